@@ -1,0 +1,155 @@
+"""Oracle: typed-graph network arithmetic (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+Restates, in numpy and for any float dtype:
+  * third-party primitives the reference calls (source NOT under /root/reference;
+    dm-haiku / jraph / jax are un-pinned, ``setup.py:37,42,43`` -- published
+    semantics restated, **parity unpinned**):
+      ``linear``      hk.Linear: ``x @ w + b``, ``w`` stored [in, out]
+      ``mlp``         hk.nets.MLP(activate_final=False) (call site
+                      ``deep_typed_graph_net.py:205-209``)
+      ``layer_norm``  hk.LayerNorm(axis=-1, create_scale, create_offset), eps=1e-5,
+                      biased variance (call site ``:231-233``)
+      ``swish``       jax.nn.swish = x * sigmoid(x) (``:444-449``)
+      ``segment_sum`` jraph.segment_sum (``:455-458``)
+      concatenated_args: concat of the positional args' leaves on the last axis
+  * ``DeepTypedGraphNet`` forward (``deep_typed_graph_net.py:180-401``) on a plain
+    dict graph: embed (GraphMapFeatures, ``typed_graph_net.py:657-696``), N
+    InteractionNetwork steps (``typed_graph_net.py:272-350,369-546,590-654``:
+    all edge sets first, then all node sets using the UPDATED edges, sent
+    messages dropped) with residuals on every node and edge set
+    (``deep_typed_graph_net.py:372-393``), optional decoder MLPs without
+    LayerNorm (``:313-322``).
+
+Graph container (all features are [rows, batch, channels] like the reference):
+  graph = {"nodes": {name: features},
+           "edges": {name: dict(senders_set, receivers_set, senders, receivers,
+                                features)}}
+"""
+import numpy as np
+import scipy.sparse
+
+LN_EPS = 1e-5   # haiku default; no in-tree override (dense.py:182-188)
+
+
+def swish(x):
+  return x / (1.0 + np.exp(-x))
+
+
+def linear(x, w, b):
+  return x @ w + b
+
+
+def mlp(x, layers):
+  """layers = [(w0, b0), (w1, b1), ...]; swish between, none after the last."""
+  for i, (w, b) in enumerate(layers):
+    x = linear(x, w, b)
+    if i < len(layers) - 1:
+      x = swish(x)
+  return x
+
+
+def layer_norm(x, scale, offset, eps=LN_EPS):
+  mean = x.mean(axis=-1, keepdims=True)
+  var = np.square(x - mean).mean(axis=-1, keepdims=True)
+  return (x - mean) / np.sqrt(var + eps) * scale + offset
+
+
+def segment_sum(data, segment_ids, num_segments):
+  """out[i] = sum_{e: ids[e] == i} data[e]; zeros for empty segments."""
+  flat = data.reshape(data.shape[0], -1)
+  sel = scipy.sparse.csr_matrix(
+      (np.ones(len(segment_ids), dtype=data.dtype),
+       (np.asarray(segment_ids), np.arange(len(segment_ids)))),
+      shape=(num_segments, len(segment_ids)))
+  return np.asarray(sel @ flat).reshape((num_segments,) + data.shape[1:])
+
+
+class Net:
+  """MLP(+LayerNorm) addressed by its reference module name."""
+
+  def __init__(self, params, gnn_name, dtype):
+    self._p, self._g, self._dt = params, gnn_name, dtype
+
+  def _get(self, module, leaf):
+    key = f"{self._g}/~_networks_builder/{module}"
+    return np.asarray(self._p[key][leaf], dtype=self._dt)
+
+  def has(self, name):
+    return f"{self._g}/~_networks_builder/{name}_mlp/~/linear_0" in self._p
+
+  def apply(self, name, *args, use_layer_norm=True):
+    x = np.concatenate(args, axis=-1) if len(args) > 1 else args[0]
+    layers, k = [], 0
+    while f"{self._g}/~_networks_builder/{name}_mlp/~/linear_{k}" in self._p:
+      layers.append((self._get(f"{name}_mlp/~/linear_{k}", "w"),
+                     self._get(f"{name}_mlp/~/linear_{k}", "b")))
+      k += 1
+    y = mlp(x, layers)
+    if use_layer_norm:
+      y = layer_norm(y, self._get(f"{name}_layer_norm", "scale"),
+                     self._get(f"{name}_layer_norm", "offset"))
+    return y
+
+
+def _edge_update(net, name, edge, nodes, chunk):
+  """e' = f([e | h_send[senders] | h_recv[receivers]]), row-chunked."""
+  e = edge["features"]
+  hs, hr = nodes[edge["senders_set"]], nodes[edge["receivers_set"]]
+  pieces = []
+  for lo in range(0, e.shape[0], chunk):
+    hi = min(lo + chunk, e.shape[0])
+    pieces.append(net.apply(name, e[lo:hi], hs[edge["senders"][lo:hi]],
+                            hr[edge["receivers"][lo:hi]]))
+  return np.concatenate(pieces, axis=0)
+
+
+def deep_typed_graph_net(params, gnn_name, graph, *, num_steps, embed_nodes,
+                         embed_edges, node_output=(), dtype=np.float64,
+                         chunk=1 << 16, live_nodes=None, live_edges=None):
+  """Returns {"nodes": {...}, "edges": {...}} of output features.
+
+  ``live_nodes`` / ``live_edges`` optionally restrict which outputs are computed
+  on the LAST step (the reference computes everything; GraphCast only reads
+  some of it -- ``graphcast.py:602-603,639,676``).  Results that are computed
+  are identical either way.
+  """
+  net = Net(params, gnn_name, dtype)
+  nodes = {k: np.asarray(v, dtype=dtype) for k, v in graph["nodes"].items()}
+  edges = {k: dict(v, features=np.asarray(v["features"], dtype=dtype))
+           for k, v in graph["edges"].items()}
+
+  # _embed (deep_typed_graph_net.py:325-353)
+  if embed_edges:
+    for k, e in edges.items():
+      e["features"] = net.apply(f"encoder_edges_{k}", e["features"])
+  if embed_nodes:
+    for k in nodes:
+      nodes[k] = net.apply(f"encoder_nodes_{k}", nodes[k])
+
+  # _process (:355-393)
+  for step in range(num_steps):
+    last = step == num_steps - 1
+    new_edges = {k: _edge_update(net, f"processor_edges_{step}_{k}", e, nodes, chunk)
+                 for k, e in edges.items()}
+    new_nodes = {}
+    for k, h in nodes.items():
+      if last and live_nodes is not None and k not in live_nodes:
+        continue
+      received = [segment_sum(new_edges[ek], e["receivers"], h.shape[0])
+                  for ek, e in sorted(edges.items()) if e["receivers_set"] == k]
+      new_nodes[k] = net.apply(f"processor_nodes_{step}_{k}", h, *received)
+    for k in list(nodes):
+      if k in new_nodes:
+        nodes[k] = nodes[k] + new_nodes[k]
+      else:
+        del nodes[k]
+    for k, e in edges.items():
+      if last and live_edges is not None and k not in live_edges:
+        e["features"] = None
+      else:
+        e["features"] = e["features"] + new_edges[k]
+
+  # _output (:395-401)
+  for k in node_output:
+    nodes[k] = net.apply(f"decoder_nodes_{k}", nodes[k], use_layer_norm=False)
+  return {"nodes": nodes, "edges": {k: e["features"] for k, e in edges.items()}}

@@ -1,0 +1,69 @@
+"""Oracle: parameter tree of the three GNNs (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+haiku's module-naming rules applied to the names built at
+``/root/reference/weathernext/utils/legacy/deep_typed_graph_net.py:205-323`` inside
+modules named ``grid2mesh_gnn`` / ``mesh_gnn`` / ``mesh2grid_gnn``
+(``weathernext1_graph/graphcast.py:217,233,261``):
+
+  "<gnn>/~_networks_builder/<prefix><set>_mlp/~/linear_<k>"  -> {"w" [in,out], "b" [out]}
+  "<gnn>/~_networks_builder/<prefix><set>_layer_norm"        -> {"scale", "offset"}
+
+Default initialisation restates hk.Linear's defaults
+(w ~ TruncatedNormal(stddev=1/sqrt(fan_in), +-2 sigma), b = 0) and
+hk.LayerNorm's (scale = 1, offset = 0); corroborated in-tree by
+``utils/dense.py:450-517``.
+"""
+import numpy as np
+from scipy import stats
+
+
+def module_specs(c_in, c_out, latent, steps, n_struct_node=3, n_struct_edge=4):
+  """[(module stem, [layer sizes incl. input], has_layer_norm)], haiku order-free."""
+  d = latent
+  specs = []
+  def add(gnn, stem, fan_in, out, ln=True):
+    specs.append((f"{gnn}/~_networks_builder/{stem}", [fan_in, d, out], ln))
+  g = "grid2mesh_gnn"
+  add(g, "encoder_edges_grid2mesh", n_struct_edge, d)
+  add(g, "encoder_nodes_grid_nodes", c_in + n_struct_node, d)
+  add(g, "encoder_nodes_mesh_nodes", c_in + n_struct_node, d)
+  add(g, "processor_edges_0_grid2mesh", 3 * d, d)
+  add(g, "processor_nodes_0_grid_nodes", d, d)
+  add(g, "processor_nodes_0_mesh_nodes", 2 * d, d)
+  g = "mesh_gnn"
+  add(g, "encoder_edges_mesh", n_struct_edge, d)
+  for i in range(steps):
+    add(g, f"processor_edges_{i}_mesh", 3 * d, d)
+    add(g, f"processor_nodes_{i}_mesh_nodes", 2 * d, d)
+  g = "mesh2grid_gnn"
+  add(g, "encoder_edges_mesh2grid", n_struct_edge, d)
+  add(g, "processor_edges_0_mesh2grid", 3 * d, d)
+  add(g, "processor_nodes_0_grid_nodes", 2 * d, d)
+  add(g, "processor_nodes_0_mesh_nodes", d, d)
+  add(g, "decoder_nodes_grid_nodes", d, c_out, ln=False)
+  return specs
+
+
+def init_params(c_in, c_out, latent, steps, seed=1, nontrivial=False):
+  """float32 haiku-layout params.  ``nontrivial`` also randomises b / scale / offset."""
+  rng = np.random.default_rng(seed)
+  params = {}
+  for stem, sizes, ln in module_specs(c_in, c_out, latent, steps):
+    for k in range(len(sizes) - 1):
+      fan_in, fan_out = sizes[k], sizes[k + 1]
+      u = rng.random((fan_in, fan_out))
+      w = stats.truncnorm.ppf(u, -2.0, 2.0) / np.sqrt(fan_in)
+      b = (0.1 * rng.standard_normal(fan_out) if nontrivial else np.zeros(fan_out))
+      params[f"{stem}_mlp/~/linear_{k}"] = {
+          "w": w.astype(np.float32), "b": b.astype(np.float32)}
+    if ln:
+      scale = 1.0 + (0.1 * rng.standard_normal(sizes[-1]) if nontrivial else 0.0)
+      offset = 0.1 * rng.standard_normal(sizes[-1]) if nontrivial else np.zeros(sizes[-1])
+      params[f"{stem}_layer_norm"] = {
+          "scale": (np.zeros(sizes[-1]) + scale).astype(np.float32),
+          "offset": np.asarray(offset).astype(np.float32)}
+  return params
+
+
+def count(params):
+  return sum(int(np.prod(a.shape)) for m in params.values() for a in m.values())
