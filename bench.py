@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- 6-h GraphCast steps/s at 0.25 deg / 37 levels on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one encode-process-decode pass (Grid2Mesh encoder, 16-step multi-mesh
+processor, Mesh2Grid decoder) over one synthetic 0.25 deg / 37-level state that
+is already resident in HBM: x [1,038,240, 1, 471] fp32 -> y [1,038,240, 1, 227].
+With N > 1 every rank advances its own ensemble member (BASELINE.json config 4;
+members never interact in the forward pass, reference rollout.py:220-283), so
+scaling is weak and `value` = N*K / max-over-ranks time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: `roofline` for the dominant kernel and `cpu_baseline` (the numpy oracle
+timed on the host cores on a bounded sample, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+LATENT = 512
+
+CONFIGS = {
+    # name: (resolution, mesh_size, levels, gnn steps)
+    "0.25deg_37L_M6": (0.25, 6, 37, 16),
+    "1deg_13L_M5": (1.0, 5, 13, 16),
+    "4deg_13L_M3": (4.0, 3, 13, 3),          # plumbing / CI only
+}
+
+
+def flops_as_written(n_grid, n_mesh, e_g2m, e_mesh, e_m2g, c_in, c_out, steps, d=LATENT):
+  """2*MAC of every MLP the reference executes per step, dead code removed."""
+  mlp = lambda rows, k, n_out: 2.0 * rows * (k * d + d * n_out)
+  return (mlp(n_grid, c_in + 3, d) + mlp(n_mesh, c_in + 3, d) + mlp(e_g2m, 4, d)
+          + mlp(e_g2m, 3 * d, d) + mlp(n_mesh, 2 * d, d) + mlp(n_grid, d, d)
+          + mlp(e_mesh, 4, d) + steps * (mlp(e_mesh, 3 * d, d) + mlp(n_mesh, 2 * d, d))
+          + mlp(e_m2g, 4, d) + mlp(e_m2g, 3 * d, d) + mlp(n_grid, 2 * d, d)
+          + mlp(n_grid, d, c_out))
+
+
+def fast_params(c_in, c_out, steps, seed=1):
+  """Random-init weights of the architecture in the reference's haiku layout."""
+  from graphcast_amd import params as gparams
+  return gparams.random_params(c_in, c_out, LATENT, steps, seed=seed)
+
+
+def op_flops(op, c_out_exec=240):
+  """FLOPs one fused launch executes (2*MAC of its GEMMs over its logical rows)."""
+  from graphcast_amd import _native as nat
+  if op.kind != nat.OP_ROWMLP:
+    return 0.0
+  m = op.mlp
+  f = 2.0 * m.n_rows * (m.k0 + m.k1) * LATENT
+  if m.mode == nat.MODE_MLP_LN:
+    f += 2.0 * m.n_rows * LATENT * LATENT
+  elif m.mode == nat.MODE_MLP_OUT:
+    f += 2.0 * m.n_rows * LATENT * c_out_exec
+  return f
+
+
+def cpu_baseline(c_in, c_out, steps, sample_cfg, f_full, threads):
+  """Times the numpy oracle (fp32, BLAS threads = host cores) on a bounded sample."""
+  from oracle import graphcast as ogc
+  res, mesh_size, _, _ = CONFIGS[sample_cfg]
+  lat = np.arange(-90, 90 + res / 2, res)
+  lon = np.arange(0, 360, res)
+  graphs = ogc.build_graphs(lat, lon, mesh_size)
+  params = fast_params(c_in, c_out, steps)
+  x = np.random.default_rng(0).standard_normal((graphs["n_grid"], 1, c_in)).astype(np.float32)
+  t0 = time.perf_counter()
+  ogc.forward(params, graphs, x, steps=steps, dtype=np.float32)
+  dt = time.perf_counter() - t0
+  f_sample = flops_as_written(graphs["n_grid"], graphs["n_mesh"], len(graphs["g2m"]["senders"]),
+                              len(graphs["mesh"]["senders"]), len(graphs["m2g"]["senders"]),
+                              c_in, c_out, steps)
+  est_full = dt * f_full / f_sample
+  return {
+      "value": 1.0 / est_full, "unit": "steps/s", "cores": threads, "kind": "port",
+      "sample": (f"numpy fp32 restatement of the reference step (JAX not installable) with the "
+                 f"0.25deg/37L channel widths on the {sample_cfg.split('_')[0]}/M{mesh_size} graph: "
+                 f"{f_sample / 1e12:.2f} TFLOP in {dt:.1f} s, scaled by the as-written FLOP ratio "
+                 f"{f_full / f_sample:.2f} to one 0.25deg step ({est_full:.0f} s)"),
+      "sample_seconds": dt}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=5)
+  ap.add_argument("--warmup", type=int, default=1)
+  ap.add_argument("--config", default="0.25deg_37L_M6", choices=sorted(CONFIGS))
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-sample", default="1deg_13L_M5", choices=sorted(CONFIGS))
+  ap.add_argument("--op-timing-iters", type=int, default=2)
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from graphcast_amd import _native as nat
+  from graphcast_amd import engine as eng
+  from graphcast_amd import graphcast as gc
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                     "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
+  torch.cuda.set_device(local_rank)
+  device = f"cuda:{local_rank}"
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world,
+                            device_id=torch.device(device))
+
+  res, mesh_size, levels, gnn_steps = CONFIGS[args.config]
+  task = {37: gc.TASK, 13: gc.TASK_13}[levels]
+  c_out = gc.num_output_channels(task)
+  c_in = 2 * (5 + 6 * levels) + 2 * 5 + 2 + 5    # 2 input frames + forcings(2 frames) + statics + target-time forcings
+  lat = np.arange(-90, 90 + res / 2, res)
+  lon = np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=LATENT,
+                       gnn_msg_steps=gnn_steps, hidden_layers=1,
+                       radius_query_fraction_edge_length=0.6)
+  t_setup = time.perf_counter()
+  model = gc.GraphCast(cfg, task, params=fast_params(c_in, c_out, gnn_steps), device=device)
+  model.init_from_coordinates(lat, lon)
+  g = model.graph_arrays()
+  n_grid = g["n_grid"]
+  # ensemble member `rank`: its own synthetic (already normalised) state, resident in HBM
+  x = torch.from_numpy(np.random.default_rng(rank).standard_normal(
+      (n_grid, 1, c_in), dtype=np.float32)).to(device)
+  y = torch.empty((n_grid, 1, c_out), dtype=torch.float32, device=device)
+  model.forward_grid_node_features(x, y)          # builds the engine + folds constants
+  torch.cuda.synchronize()
+  t_setup = time.perf_counter() - t_setup
+  engine = model._engine
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    engine(x, y)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    engine(x, y)
+  barrier()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  finite = bool(torch.isfinite(y).all().item())
+
+  if rank == 0:
+    ms_per_step = 1e3 * elapsed / args.steps
+    f_alg = flops_as_written(n_grid, g["n_mesh"], len(g["g2m"]["senders"]),
+                             len(g["mesh"]["senders"]), len(g["m2g"]["senders"]),
+                             c_in, c_out, gnn_steps)
+    # per-kernel durations, HIP events on the launch stream (gc_time_program)
+    arr, _ = engine.bind(x, y)
+    timed = engine.time_ops(x, iters=args.op_timing_iters)
+    tag_name = {v: k for k, v in eng.TAGS.items()}
+    per_stage = {}
+    for k, (tag, kind, ms) in enumerate(timed):
+      s = per_stage.setdefault(tag_name[tag], {"ms": 0.0, "launches": 0, "tflop": 0.0})
+      s["ms"] += ms
+      s["launches"] += 1
+      s["tflop"] += op_flops(arr[k]) / 1e12
+    dominant = max(per_stage, key=lambda s: per_stage[s]["ms"])
+    dom = per_stage[dominant]
+    achieved = dom["tflop"] / (dom["ms"] / 1e3) if dom["ms"] > 0 else 0.0
+    executed_tflop = sum(s["tflop"] for s in per_stage.values())
+    line = {
+        "metric": "6-h rollout steps/sec at 0.25deg/37-level",
+        "value": args.gpus * args.steps / elapsed,
+        "unit": "steps/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"GraphCast {args.config}: one encode-process-decode 6-h step per GPU "
+                        f"(grid {n_grid}, mesh {g['n_mesh']}, edges {len(g['g2m']['senders'])}/"
+                        f"{len(g['mesh']['senders'])}/{len(g['m2g']['senders'])}, C {c_in}->{c_out}, "
+                        f"{gnn_steps} processor steps, latent 512), random-init weights",
+            "parallelism": f"ensemble x{args.gpus} (1 member per GPU, no collective in the step)",
+            "batch_per_gpu": 1},
+        "roofline": {
+            "bound": "mfma", "kernel": f"rowmlp_kernel<MLP_LN> stage {dominant}",
+            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "launches_per_step": dom["launches"],
+            "avg_launch_ms": dom["ms"] / dom["launches"],
+            "traffic": None,
+            "step_executed_tflop": executed_tflop,
+            "step_as_written_tflop": f_alg / 1e12,
+            "step_frac_executed": executed_tflop / (ms_per_step / 1e3) / PEAK_FP32_MFMA_TFLOPS,
+            "step_frac_as_written": f_alg / 1e12 / (ms_per_step / 1e3) / PEAK_FP32_MFMA_TFLOPS},
+        "stages_ms": {k: round(v["ms"], 3) for k, v in sorted(per_stage.items())},
+        "setup_seconds": round(t_setup, 1),
+        "output_finite": finite,
+        "build": nat.lib().gc_build_info().decode(),
+    }
+    if args.gpus == 1 and not args.no_cpu_baseline:
+      threads = os.cpu_count() or 1
+      torch.set_num_threads(threads)
+      line["cpu_baseline"] = cpu_baseline(c_in, c_out, gnn_steps, args.cpu_sample, f_alg, threads)
+    else:
+      line["cpu_baseline"] = None
+    print(json.dumps(line))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

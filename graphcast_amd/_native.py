@@ -1,0 +1,133 @@
+"""ctypes binding of libgcast_hip.so (the C-ABI declared in include/gcast.h).
+
+There is deliberately no fallback: if the library is missing or does not load
+the import fails loudly -- the product path never computes on the CPU.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
+OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
+LATENT = 512
+TILE_ROWS = 64
+K_CHUNK = 32
+
+_fp = ctypes.c_void_p     # device pointers travel as integers
+
+
+class RowMlpDesc(ctypes.Structure):
+  """struct gc_rowmlp_desc (include/gcast.h) -- field order must match exactly."""
+  _fields_ = [
+      ("mode", ctypes.c_int), ("n_rows", ctypes.c_int),
+      ("a0", _fp), ("lda0", ctypes.c_int), ("k0", ctypes.c_int),
+      ("a1", _fp), ("lda1", ctypes.c_int), ("k1", ctypes.c_int),
+      ("w1p", _fp),
+      ("d", _fp), ("ldd", ctypes.c_int),
+      ("g0", _fp), ("idx0", _fp),
+      ("g1", _fp), ("idx1", _fp),
+      ("b1", _fp),
+      ("w2p", _fp), ("b2", _fp), ("n2", ctypes.c_int),
+      ("ln_scale", _fp), ("ln_offset", _fp),
+      ("res", _fp), ("ldres", ctypes.c_int),
+      ("out", _fp), ("ldo", ctypes.c_int),
+      ("seg", _fp), ("tile_flags", _fp), ("agg", _fp), ("partial", _fp),
+  ]
+
+
+class Op(ctypes.Structure):
+  """struct gc_op."""
+  _fields_ = [
+      ("kind", ctypes.c_int), ("tag", ctypes.c_int),
+      ("mlp", RowMlpDesc),
+      ("n", ctypes.c_int), ("i0", _fp), ("i1", _fp), ("i2", _fp),
+      ("src", _fp), ("dst", _fp),
+      ("batch", ctypes.c_int), ("b", ctypes.c_int), ("c_in", ctypes.c_int),
+      ("n_struct", ctypes.c_int), ("kp", ctypes.c_int),
+      ("x", _fp), ("node_struct", _fp),
+  ]
+
+
+EXPORTS = ("gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
+           "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
+
+
+def library_path(variant=None):
+  variant = variant or os.environ.get("GCAST_LIB_VARIANT", "glds")
+  name = {"glds": "libgcast_hip.so", "regs": "libgcast_hip_regs.so"}[variant]
+  return os.path.join(_CSRC, name)
+
+
+def build(force=False, verbose=False):
+  """Compiles csrc/gcast.hip for gfx950 with hipcc (both LDS-staging variants)."""
+  src = os.path.join(_CSRC, "gcast.hip")
+  hdr = os.path.join(_INCLUDE, "gcast.h")
+  newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+  for variant, define in (("glds", "-DGC_STAGE_GLDS=1"), ("regs", "-DGC_STAGE_GLDS=0")):
+    out = library_path(variant)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+      continue
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value",
+           define, "-I", _INCLUDE, "-shared", "-fPIC", src, "-o", out]
+    if verbose:
+      print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+
+
+_lib = None
+
+
+def lib():
+  """Loads the library once.  torch must be imported first so that the HIP runtime
+  already in the process (torch's libamdhip64.so.7) is the one the kernels bind to."""
+  global _lib
+  if _lib is None:
+    import torch  # noqa: F401  (loads libamdhip64 into the process)
+    path = library_path()
+    if not os.path.exists(path):
+      raise RuntimeError(
+          f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    l = ctypes.CDLL(path)
+    l.gc_rowmlp.argtypes = [ctypes.POINTER(RowMlpDesc), ctypes.c_void_p]
+    l.gc_seg_fixup.argtypes = [ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_void_p]
+    l.gc_zero_rows.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_void_p]
+    l.gc_prep_grid_input.argtypes = [ctypes.c_int] * 4 + [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp,
+                                                          ctypes.c_void_p]
+    l.gc_run_program.argtypes = [ctypes.POINTER(Op), ctypes.c_int, ctypes.c_void_p]
+    l.gc_time_program.argtypes = [ctypes.POINTER(Op), ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
+    for name in ("gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
+                 "gc_run_program", "gc_time_program"):
+      getattr(l, name).restype = ctypes.c_int
+    l.gc_last_error.restype = ctypes.c_char_p
+    l.gc_abi_sizeof.argtypes = [ctypes.c_int]
+    l.gc_abi_sizeof.restype = ctypes.c_size_t
+    if (l.gc_abi_sizeof(0) != ctypes.sizeof(RowMlpDesc) or l.gc_abi_sizeof(1) != ctypes.sizeof(Op)):
+      raise RuntimeError("ctypes struct layout does not match include/gcast.h "
+                         f"({l.gc_abi_sizeof(0)}/{ctypes.sizeof(RowMlpDesc)}, "
+                         f"{l.gc_abi_sizeof(1)}/{ctypes.sizeof(Op)}); rebuild the library")
+    l.gc_build_info.restype = ctypes.c_char_p
+    _lib = l
+  return _lib
+
+
+class GcastError(RuntimeError):
+  pass
+
+
+def check(rc, what):
+  if rc != 0:
+    raise GcastError(f"{what} failed ({rc}): {lib().gc_last_error().decode()}")
+
+
+def ptr(t):
+  """Device pointer of a torch tensor (or None -> NULL)."""
+  if t is None:
+    return None
+  return t.data_ptr()

@@ -1,0 +1,543 @@
+// gcast.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI for GraphCast's
+// encode-process-decode step.  See include/gcast.h for the interface and
+// DESIGN.md for the design.  fp32 throughout (exact-fp32 MFMA, 157 TF peak).
+//
+// The one hot kernel is `rowmlp_kernel`: a 64-row tile (4 waves x 16 rows) is
+// pushed through  z = A.W1 + addends -> swish -> .W2 + b2 -> LayerNorm
+// [-> + residual] [-> receiver segment-sum]  without leaving the CU.
+//
+// "Transposed, register-chained" MFMA formulation (v_mfma_f32_16x16x4_f32):
+//   C^T[n][m] += sum_k W^T[n][k] * X^T[k][m]
+//   A operand  = weights: lane l supplies W[k = kb + 4*(l>>4) + j][n = 16*nb + (l&15)]
+//   B operand  = rows:    lane l supplies X[row = l&15][k = kb + 4*(l>>4) + j]
+//   C/D        : lane l, reg r holds out[row = l&15][n = 16*nb + 4*(l>>4) + r]
+// so the 4 accumulator registers of block nb' are, as they sit, the B operands
+// of the NEXT layer's k-steps kb = 16*nb' (j = r): the hidden activations never
+// touch LDS or HBM.  Weights stream through LDS in 32-row K chunks laid out
+// [k/4][n][k%4] (packed on the host), DMA'd linearly with global_load_lds and
+// read as conflict-free ds_read_b128 (slot index == n mod 16 within a lane group).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "gcast.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#ifndef GC_STAGE_GLDS
+#define GC_STAGE_GLDS 1
+#endif
+
+namespace {
+
+constexpr int kD = GC_LATENT;            // 512
+constexpr int kNB = kD / 16;             // 32 n-blocks of 16
+constexpr int kBufFloats = 8 * kD * 4;   // one LDS weight buffer: 8 k4-groups x 512 n x 4 = 64 KiB
+constexpr int kYld = kD + 4;             // padded row stride of the segment-sum staging tile
+constexpr int kLdsFloats = GC_TILE_ROWS * kYld + GC_TILE_ROWS;   // Y tile (aliases both buffers) + seg ids
+constexpr float kLnEps = 1e-5f;          // haiku LayerNorm default
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+  std::snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Copies one K chunk of packed weights (8 * NP * 4 floats, contiguous) into LDS.
+template <int NP>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ gsrc, float* lds, int tid) {
+  constexpr int kFloats = 8 * NP * 4;
+  static_assert(kFloats % 1024 == 0, "chunk must be a whole number of 4 KiB block copies");
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+  for (int it = 0; it < kFloats / 1024; ++it) {
+    const int off = it * 1024 + wave * 256;     // wave-uniform float offset of this 1 KiB piece
+#if GC_STAGE_GLDS
+    // LDS destination = wave-uniform base + lane * 16 B (linear image).
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(gsrc + off + lane * 4),
+        (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+#else
+    const f4 v = *reinterpret_cast<const f4*>(gsrc + off + lane * 4);
+    *reinterpret_cast<f4*>(lds + off + lane * 4) = v;
+#endif
+  }
+}
+
+// acc[nb] += W-chunk(32 k) * B for all n-blocks; b0/b1 are the B operands of the
+// two 16-k halves.  Blocks are processed in pairs so that dependent MFMAs on one
+// accumulator are 2 issue slots apart (40-cycle dependent latency vs 32-cycle issue).
+template <int NBLK, int NP>
+__device__ __forceinline__ void mma_chunk(f4 (&acc)[kNB], const float* wb, f4 b0, f4 b1,
+                                          int i, int g) {
+  static_assert(NBLK % 2 == 1 || NBLK % 2 == 0, "");
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const f4 b = s ? b1 : b0;
+    const float* base = wb + (((s * 4 + g) * NP + i) << 2);
+#pragma unroll
+    for (int nb = 0; nb + 1 < NBLK; nb += 2) {
+      const f4 a0 = *reinterpret_cast<const f4*>(base + (nb * 16 << 2));
+      const f4 a1 = *reinterpret_cast<const f4*>(base + ((nb + 1) * 16 << 2));
+      acc[nb] = mfma16(a0.x, b.x, acc[nb]);
+      acc[nb + 1] = mfma16(a1.x, b.x, acc[nb + 1]);
+      acc[nb] = mfma16(a0.y, b.y, acc[nb]);
+      acc[nb + 1] = mfma16(a1.y, b.y, acc[nb + 1]);
+      acc[nb] = mfma16(a0.z, b.z, acc[nb]);
+      acc[nb + 1] = mfma16(a1.z, b.z, acc[nb + 1]);
+      acc[nb] = mfma16(a0.w, b.w, acc[nb]);
+      acc[nb + 1] = mfma16(a1.w, b.w, acc[nb + 1]);
+    }
+    if (NBLK & 1) {
+      constexpr int nb = NBLK - 1;
+      const f4 a0 = *reinterpret_cast<const f4*>(base + (nb * 16 << 2));
+      acc[nb] = mfma16(a0.x, b.x, acc[nb]);
+      acc[nb] = mfma16(a0.y, b.y, acc[nb]);
+      acc[nb] = mfma16(a0.z, b.z, acc[nb]);
+      acc[nb] = mfma16(a0.w, b.w, acc[nb]);
+    }
+  }
+}
+
+__device__ __forceinline__ float swish1(float x) {
+  // x * sigmoid(x); __expf/fast reciprocal are ~1-2 ulp, far inside the 1e-4 budget.
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
+__device__ __forceinline__ float group_sum4(float v) {
+  // sum over the 4 lanes {l, l^16, l^32, l^48} that share one row
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool kLinear = MODE == GC_MODE_LINEAR;
+  constexpr int NP2 = MODE == GC_MODE_MLP_OUT ? 256 : 512;
+  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i = lane & 15;          // row within the wave's 16 (B/C column), n within block (A row)
+  const int g = lane >> 4;          // k sub-group (A/B), n sub-group (C)
+  const int tile = blockIdx.x;
+  const int row = tile * GC_TILE_ROWS + wave * 16 + i;
+  const int rowc = row < d.n_rows ? row : d.n_rows - 1;
+  const int col0 = 4 * g;           // this lane's first column inside a 16-wide n block
+
+  const int n1 = (d.k0 + d.k1) >> 5;
+  const int n1a = d.k0 >> 5;
+  int q = 0;                        // position in the weight-chunk stream -> LDS buffer parity
+
+  if (n1 > 0) {
+    stage_chunk<512>(d.w1p, smem, tid);
+  } else if (!kLinear) {
+    stage_chunk<NP2>(d.w2p, smem, tid);
+  }
+
+  // ---- layer-1 accumulators start from the addends -------------------------------
+  f4 acc[kNB];
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+  if (d.b1) {
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(d.b1 + nb * 16 + col0);
+  }
+  if (d.d) {
+    const float* p = d.d + (size_t)rowc * d.ldd + col0;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(p + nb * 16);
+  }
+  if (d.g0) {
+    int ix = d.idx0[rowc];
+    ix = ix < 0 ? 0 : ix;
+    const float* p = d.g0 + (size_t)ix * kD + col0;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(p + nb * 16);
+  }
+  if (d.g1) {
+    int ix = d.idx1[rowc];
+    ix = ix < 0 ? 0 : ix;
+    const float* p = d.g1 + (size_t)ix * kD + col0;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(p + nb * 16);
+  }
+
+  // ---- layer 1: acc += A . W1, A rows streamed from global as B operands ---------
+  if (n1 > 0) {
+    const float* arow0 = d.a0 + (size_t)rowc * d.lda0 + col0;
+    const float* arow1 = d.k1 ? d.a1 + (size_t)rowc * d.lda1 + col0 : arow0;
+    f4 bc0, bc1, bn0, bn1;
+    {
+      const float* p = n1a > 0 ? arow0 : arow1;
+      bc0 = *reinterpret_cast<const f4*>(p);
+      bc1 = *reinterpret_cast<const f4*>(p + 16);
+    }
+    bn0 = bc0;
+    bn1 = bc1;
+    for (int c = 0; c < n1; ++c) {
+      __syncthreads();   // chunk c landed in LDS; previous chunk's readers are done
+      if (c + 1 < n1) {
+        stage_chunk<512>(d.w1p + (size_t)(c + 1) * kBufFloats, smem + ((q + 1) & 1) * kBufFloats, tid);
+        const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
+        bn0 = *reinterpret_cast<const f4*>(p);
+        bn1 = *reinterpret_cast<const f4*>(p + 16);
+      } else if (!kLinear) {
+        stage_chunk<NP2>(d.w2p, smem + ((q + 1) & 1) * kBufFloats, tid);
+      }
+      mma_chunk<kNB, 512>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g);
+      bc0 = bn0;
+      bc1 = bn1;
+      ++q;
+    }
+  }
+
+  if (kLinear) {
+    if (row < d.n_rows) {
+      float* o = d.out + (size_t)row * d.ldo + col0;
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb) *reinterpret_cast<f4*>(o + nb * 16) = acc[nb];
+    }
+    return;
+  }
+
+  // ---- swish in place: acc becomes the hidden layer, already in B-operand layout -
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) {
+    acc[nb].x = swish1(acc[nb].x);
+    acc[nb].y = swish1(acc[nb].y);
+    acc[nb].z = swish1(acc[nb].z);
+    acc[nb].w = swish1(acc[nb].w);
+  }
+
+  // ---- layer 2: out = hidden . W2 + b2 (fully unrolled: hidden regs are indexed by chunk)
+  f4 o2[kNB];
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb) o2[nb] = *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
+#pragma unroll
+  for (int cc = 0; cc < kD / 32; ++cc) {
+    __syncthreads();
+    if (cc + 1 < kD / 32) {
+      stage_chunk<NP2>(d.w2p + (size_t)(cc + 1) * (8 * NP2 * 4), smem + ((q + 1) & 1) * kBufFloats, tid);
+    }
+    mma_chunk<NB2, NP2>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g);
+    ++q;
+  }
+
+  if (MODE == GC_MODE_MLP_OUT) {
+    if (row < d.n_rows) {
+      float* o = d.out + (size_t)row * d.ldo;
+#pragma unroll
+      for (int nb = 0; nb < NB2; ++nb) {
+        const int n = nb * 16 + col0;
+        if (n + 0 < d.n2) o[n + 0] = o2[nb].x;
+        if (n + 1 < d.n2) o[n + 1] = o2[nb].y;
+        if (n + 2 < d.n2) o[n + 2] = o2[nb].z;
+        if (n + 3 < d.n2) o[n + 3] = o2[nb].w;
+      }
+    }
+    return;
+  }
+
+  // ---- LayerNorm over the 512 outputs of each row (128 per lane x 4 lanes) -------
+  if (d.ln_scale) {
+    float s = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) s += (o2[nb].x + o2[nb].y) + (o2[nb].z + o2[nb].w);
+    const float mean = group_sum4(s) * (1.0f / kD);
+    float v = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) {
+      o2[nb] -= mean;
+      v += (o2[nb].x * o2[nb].x + o2[nb].y * o2[nb].y) + (o2[nb].z * o2[nb].z + o2[nb].w * o2[nb].w);
+    }
+    const float rstd = rsqrtf(group_sum4(v) * (1.0f / kD) + kLnEps);
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) {
+      const f4 sc = *reinterpret_cast<const f4*>(d.ln_scale + nb * 16 + col0);
+      const f4 of = *reinterpret_cast<const f4*>(d.ln_offset + nb * 16 + col0);
+      o2[nb] = o2[nb] * rstd * sc + of;
+    }
+  }
+
+  // ---- store (with residual) -------------------------------------------------------
+  if (d.out && row < d.n_rows) {
+    float* o = d.out + (size_t)row * d.ldo + col0;
+    if (d.res) {
+      const float* r = d.res + (size_t)row * d.ldres + col0;
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb)
+        *reinterpret_cast<f4*>(o + nb * 16) = o2[nb] + *reinterpret_cast<const f4*>(r + nb * 16);
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb) *reinterpret_cast<f4*>(o + nb * 16) = o2[nb];
+    }
+  }
+
+  // ---- deterministic segment-sum over the tile's receiver-sorted rows -------------
+  if (d.seg) {
+    float* ytile = smem;
+    int* segs = reinterpret_cast<int*>(smem + GC_TILE_ROWS * kYld);
+    __syncthreads();   // all waves are done with the weight buffers
+    {
+      float* y = ytile + (wave * 16 + i) * kYld + col0;
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb) *reinterpret_cast<f4*>(y + nb * 16) = o2[nb];
+    }
+    if (tid < GC_TILE_ROWS) segs[tid] = d.seg[tile * GC_TILE_ROWS + tid];
+    __syncthreads();
+    const int flags = d.tile_flags[tile];
+    const int c2 = tid * 2;          // this thread owns columns c2, c2+1
+    float sx = 0.f, sy = 0.f;
+    int cur = -1;
+    int run_start = 0;
+    for (int r = 0; r <= GC_TILE_ROWS; ++r) {
+      const int sid = r < GC_TILE_ROWS ? segs[r] : -2;
+      if (sid != cur) {
+        if (cur >= 0) {
+          float* dst;
+          if (run_start == 0 && (flags & 1)) {
+            dst = d.partial + (size_t)(2 * tile) * kD;
+          } else if (r == GC_TILE_ROWS && (flags & 2)) {
+            dst = d.partial + (size_t)(2 * tile + 1) * kD;
+          } else {
+            dst = d.agg + (size_t)cur * kD;
+          }
+          *reinterpret_cast<float2*>(dst + c2) = make_float2(sx, sy);
+        }
+        cur = sid;
+        run_start = r;
+        sx = 0.f;
+        sy = 0.f;
+      }
+      if (sid >= 0) {
+        const float2 v = *reinterpret_cast<const float2*>(ytile + r * kYld + c2);
+        sx += v.x;
+        sy += v.y;
+      }
+    }
+  }
+}
+
+__global__ void seg_fixup_kernel(int n, const int* __restrict__ recv, const int* __restrict__ t0,
+                                 const int* __restrict__ t1, const float* __restrict__ partial,
+                                 float* __restrict__ agg) {
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  const int c = threadIdx.x * 4;    // 128 threads x 4 columns
+  const int a = t0[e], b = t1[e];
+  f4 s = *reinterpret_cast<const f4*>(partial + (size_t)(2 * a + 1) * kD + c);
+  for (int t = a + 1; t <= b; ++t) s += *reinterpret_cast<const f4*>(partial + (size_t)(2 * t) * kD + c);
+  *reinterpret_cast<f4*>(agg + (size_t)recv[e] * kD + c) = s;
+}
+
+__global__ void zero_rows_kernel(int n, const int* __restrict__ rows, float* __restrict__ agg) {
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  *reinterpret_cast<f4*>(agg + (size_t)rows[e] * kD + threadIdx.x * 4) = f4{0.f, 0.f, 0.f, 0.f};
+}
+
+__global__ void prep_grid_input_kernel(int n_rows, int batch, int b, int c_in,
+                                       const float* __restrict__ x, int n_struct,
+                                       const float* __restrict__ node_struct, int kp,
+                                       float* __restrict__ xin) {
+  // one wave per row, lanes stride over the kp output columns
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float* src = x + ((size_t)row * batch + b) * c_in;
+  const float* st = node_struct + (size_t)row * n_struct;
+  float* dst = xin + (size_t)row * kp;
+  for (int c = lane; c < kp; c += 64) {
+    float v = 0.f;
+    if (c < c_in) {
+      v = src[c];
+    } else if (c < c_in + n_struct) {
+      v = st[c - c_in];
+    }
+    dst[c] = v;
+  }
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return GC_ELAUNCH;
+  }
+  return 0;
+}
+
+bool g_attr_set[3] = {false, false, false};
+
+template <int MODE>
+int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
+  const size_t lds = kLdsFloats * sizeof(float);
+  if (!g_attr_set[MODE]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp_kernel<MODE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+      return GC_ELAUNCH;
+    }
+    g_attr_set[MODE] = true;
+  }
+  const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
+  hipLaunchKernelGGL(rowmlp_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
+  return check_launch("rowmlp_kernel");
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
+  if (!dp) return fail(GC_EINVAL, "gc_rowmlp: null descriptor");
+  const gc_rowmlp_desc& d = *dp;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
+  if ((d.k0 | d.k1) & 31 || d.k0 < 0 || d.k1 < 0) return fail(GC_EINVAL, "gc_rowmlp: k0/k1 must be multiples of 32");
+  if (d.k0 == 0 && d.k1 != 0) return fail(GC_EINVAL, "gc_rowmlp: k1 without k0");
+  if (d.k0 + d.k1 > 0 && (!d.a0 || !d.w1p)) return fail(GC_EINVAL, "gc_rowmlp: layer-1 GEMM needs a0 and w1p");
+  if (d.k1 && !d.a1) return fail(GC_EINVAL, "gc_rowmlp: k1 > 0 needs a1");
+  if ((d.k0 && (d.lda0 & 3)) || (d.k1 && (d.lda1 & 3)) || (d.d && (d.ldd & 3)))
+    return fail(GC_EINVAL, "gc_rowmlp: row strides must be multiples of 4 floats");
+  if (!aligned16(d.a0) || !aligned16(d.a1) || !aligned16(d.w1p) || !aligned16(d.d) || !aligned16(d.g0) ||
+      !aligned16(d.g1) || !aligned16(d.b1) || !aligned16(d.w2p) || !aligned16(d.b2) ||
+      !aligned16(d.ln_scale) || !aligned16(d.ln_offset) || !aligned16(d.res) ||
+      !aligned16(d.agg) || !aligned16(d.partial))
+    return fail(GC_EINVAL, "gc_rowmlp: pointers must be 16-byte aligned");
+  if ((d.g0 && !d.idx0) || (d.g1 && !d.idx1)) return fail(GC_EINVAL, "gc_rowmlp: gather without index array");
+  if (d.k0 + d.k1 == 0 && !d.d && !d.g0 && !d.g1) return fail(GC_EINVAL, "gc_rowmlp: no layer-1 input at all");
+  switch (d.mode) {
+    case GC_MODE_LINEAR:
+      if (!d.out || (d.ldo & 3) || !aligned16(d.out)) return fail(GC_EINVAL, "gc_rowmlp LINEAR: out must be 16B aligned, ldo % 4 == 0");
+      return launch_rowmlp<GC_MODE_LINEAR>(d, s);
+    case GC_MODE_MLP_LN:
+      if (!d.w2p || !d.b2 || d.n2 != kD) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: needs w2p, b2, n2 == 512");
+      if (d.ln_scale && !d.ln_offset) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: ln_scale without ln_offset");
+      if (d.out && ((d.ldo & 3) || !aligned16(d.out))) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: out alignment");
+      if (d.res && (!d.out || (d.ldres & 3))) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: residual needs out, ldres % 4 == 0");
+      if (d.seg) {
+        if (d.n_rows % GC_TILE_ROWS) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: segment-sum needs n_rows % 64 == 0");
+        if (!d.tile_flags || !d.agg || !d.partial) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: segment-sum needs tile_flags, agg, partial");
+      } else if (!d.out) {
+        return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg)");
+      }
+      return launch_rowmlp<GC_MODE_MLP_LN>(d, s);
+    case GC_MODE_MLP_OUT:
+      if (!d.w2p || !d.b2 || d.n2 <= 0 || d.n2 > 240 || !d.out) return fail(GC_EINVAL, "gc_rowmlp MLP_OUT: needs w2p, b2, out, 0 < n2 <= 240");
+      return launch_rowmlp<GC_MODE_MLP_OUT>(d, s);
+    default:
+      return fail(GC_EINVAL, "gc_rowmlp: unknown mode");
+  }
+}
+
+int gc_seg_fixup(int n, const int* recv, const int* t0, const int* t1, const float* partial,
+                 float* agg, void* stream) {
+  if (n < 0) return fail(GC_EINVAL, "gc_seg_fixup: negative count");
+  if (n == 0) return 0;
+  if (!recv || !t0 || !t1 || !partial || !agg) return fail(GC_EINVAL, "gc_seg_fixup: null pointer");
+  hipLaunchKernelGGL(seg_fixup_kernel, dim3(n), dim3(kD / 4), 0, static_cast<hipStream_t>(stream), n,
+                     recv, t0, t1, partial, agg);
+  return check_launch("seg_fixup_kernel");
+}
+
+int gc_zero_rows(int n, const int* rows, float* agg, void* stream) {
+  if (n < 0) return fail(GC_EINVAL, "gc_zero_rows: negative count");
+  if (n == 0) return 0;
+  if (!rows || !agg) return fail(GC_EINVAL, "gc_zero_rows: null pointer");
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(n), dim3(kD / 4), 0, static_cast<hipStream_t>(stream), n, rows, agg);
+  return check_launch("zero_rows_kernel");
+}
+
+int gc_prep_grid_input(int n_rows, int batch, int b, int c_in, const float* x, int n_struct,
+                       const float* node_struct, int kp, float* xin, void* stream) {
+  if (n_rows <= 0 || batch <= 0 || b < 0 || b >= batch || c_in <= 0 || n_struct < 0 ||
+      kp < c_in + n_struct || (kp & 31))
+    return fail(GC_EINVAL, "gc_prep_grid_input: bad sizes (kp must be a multiple of 32 >= c_in + n_struct)");
+  if (!x || !xin || (n_struct && !node_struct)) return fail(GC_EINVAL, "gc_prep_grid_input: null pointer");
+  const int rows_per_block = 4;
+  hipLaunchKernelGGL(prep_grid_input_kernel, dim3((n_rows + rows_per_block - 1) / rows_per_block),
+                     dim3(64 * rows_per_block), 0, static_cast<hipStream_t>(stream), n_rows, batch, b,
+                     c_in, x, n_struct, node_struct, kp, xin);
+  return check_launch("prep_grid_input_kernel");
+}
+
+static int run_op(const gc_op& op, void* stream) {
+  switch (op.kind) {
+    case GC_OP_ROWMLP:
+      return gc_rowmlp(&op.mlp, stream);
+    case GC_OP_FIXUP:
+      return gc_seg_fixup(op.n, op.i0, op.i1, op.i2, op.src, op.dst, stream);
+    case GC_OP_ZERO:
+      return gc_zero_rows(op.n, op.i0, op.dst, stream);
+    case GC_OP_PREP:
+      return gc_prep_grid_input(op.n, op.batch, op.b, op.c_in, op.x, op.n_struct, op.node_struct, op.kp,
+                                op.dst, stream);
+    default:
+      return fail(GC_EINVAL, "gc_run_program: unknown op kind");
+  }
+}
+
+int gc_run_program(const gc_op* ops, int n_ops, void* stream) {
+  if (!ops || n_ops < 0) return fail(GC_EINVAL, "gc_run_program: bad arguments");
+  for (int k = 0; k < n_ops; ++k) {
+    const int rc = run_op(ops[k], stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int gc_time_program(const gc_op* ops, int n_ops, int iters, float* h_ms, void* stream) {
+  if (!ops || n_ops <= 0 || iters <= 0 || !h_ms) return fail(GC_EINVAL, "gc_time_program: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t* ev = new hipEvent_t[n_ops + 1];
+  for (int k = 0; k <= n_ops; ++k) hipEventCreate(&ev[k]);
+  for (int k = 0; k < n_ops; ++k) h_ms[k] = 0.f;
+  int rc = 0;
+  for (int it = 0; it < iters && !rc; ++it) {
+    hipEventRecord(ev[0], s);
+    for (int k = 0; k < n_ops && !rc; ++k) {
+      rc = run_op(ops[k], stream);
+      hipEventRecord(ev[k + 1], s);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) rc = fail(GC_ELAUNCH, "gc_time_program: stream sync failed");
+    for (int k = 0; k < n_ops && !rc; ++k) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+      h_ms[k] += ms / iters;
+    }
+  }
+  for (int k = 0; k <= n_ops; ++k) hipEventDestroy(ev[k]);
+  delete[] ev;
+  return rc;
+}
+
+size_t gc_abi_sizeof(int what) {
+  return what == 0 ? sizeof(gc_rowmlp_desc) : what == 1 ? sizeof(gc_op) : 0;
+}
+
+const char* gc_last_error(void) { return g_err; }
+
+const char* gc_build_info(void) {
+#if GC_STAGE_GLDS
+  return "gfx950;stage=glds;tile=64x512;mfma=f32_16x16x4";
+#else
+  return "gfx950;stage=regs;tile=64x512;mfma=f32_16x16x4";
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+"""Device plan for one GraphCast encode-process-decode step on an MI355X.
+
+Takes the three static graphs (``graphcast.py`` builds them exactly like the
+reference's ``_init_*_graph``, weathernext1_graph/graphcast.py:408-548) and the
+haiku parameter tree, and turns them into
+  * packed, receiver-sorted edge sets (``packing.pack_edges``),
+  * k4-interleaved weights (``packing.pack_weight``) with the first edge-MLP
+    matrix split into its edge / sender / receiver row blocks
+    (W1 = [W_e; W_s; W_r] in concat order, deep_typed_graph_net.py:209 +
+    typed_graph_net.py:448-453), so the sender/receiver products are taken per
+    NODE before the gather ((x[idx]).W == (x.W)[idx]),
+  * input-independent terms folded once at load time ON THE DEVICE with the
+    same kernels (mesh-node embedding of [0 | struct], the three edge
+    embedders, and every first-layer term that only depends on them),
+  * a fixed program of fused launches (``_native.Op`` array) replayed by
+    ``gc_run_program`` for every step.
+
+All arithmetic happens in libgcast_hip.so; torch only owns the memory.
+"""
+import ctypes
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from graphcast_amd import _native as nat
+from graphcast_amd import packing
+
+D = packing.LATENT
+
+# stage tags reported by gc_time_program / used by bench.py
+TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, enc_node_grid=5,
+            proc_pre=6, proc_edge=7, proc_node=8, dec_pre=9, dec_edge=10, dec_node=11,
+            dec_out=12, fixup=13)
+
+
+class _Mlp:
+  """Packed device copy of one `<stem>_mlp` (+ `<stem>_layer_norm`)."""
+
+  def __init__(self, params, stem, dev, split=None, np2=D):
+    w1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["w"], dtype=np.float32)
+    b1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["b"], dtype=np.float32)
+    w2 = np.asarray(params[f"{stem}_mlp/~/linear_1"]["w"], dtype=np.float32)
+    b2 = np.asarray(params[f"{stem}_mlp/~/linear_1"]["b"], dtype=np.float32)
+    if f"{stem}_mlp/~/linear_2" in params:
+      raise NotImplementedError("only mlp_num_hidden_layers == 1 (GraphCast's value) is built")
+    if w1.shape[1] != D or w2.shape[0] != D:
+      raise NotImplementedError(f"latent/hidden size must be {D}, got {w1.shape}, {w2.shape}")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    self.k_in = w1.shape[0]
+    self.n_out = w2.shape[1]
+    # W1 either whole, or split into named row blocks of 512 (concat order)
+    if split is None:
+      self.w1 = up(packing.pack_weight(w1))
+      self.k1p = packing.round_up(w1.shape[0], packing.K_CHUNK)
+    else:
+      assert w1.shape[0] == D * len(split), (stem, w1.shape, split)
+      self.w1 = {name: up(packing.pack_weight(w1[j * D:(j + 1) * D])) for j, name in enumerate(split)}
+    self.b1 = up(b1)
+    self.w2 = up(packing.pack_weight(w2, np_cols=np2))
+    self.b2 = up(packing.pad_vector(b2, np2))
+    self.scale = self.offset = None
+    if f"{stem}_layer_norm" in params:
+      self.scale = up(np.asarray(params[f"{stem}_layer_norm"]["scale"], dtype=np.float32))
+      self.offset = up(np.asarray(params[f"{stem}_layer_norm"]["offset"], dtype=np.float32))
+
+
+class _Edges:
+  """Device copy of a packed edge set."""
+
+  def __init__(self, pk: packing.PackedEdges, dev):
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    self.pk = pk
+    self.n_rows = pk.n_rows
+    self.snd, self.rcv = up(pk.senders), up(pk.receivers)
+    self.flags = up(pk.tile_flags)
+    self.fix = (up(pk.fix_recv), up(pk.fix_t0), up(pk.fix_t1)) if len(pk.fix_recv) else None
+    self.empty = up(pk.empty_receivers) if len(pk.empty_receivers) else None
+    self.partial = torch.empty((2 * pk.n_rows // packing.TILE, D), dtype=torch.float32, device=dev)
+
+
+class StepEngine:
+  """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
+
+  def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
+               device="cuda:0"):
+    self.dev = torch.device(device)
+    self.lib = nat.lib()
+    self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
+    self.c_in, self.c_out, self.num_steps = c_in, c_out, num_steps
+    self.n_struct = graphs["grid_node_feat"].shape[1]
+    self.kp = packing.round_up(c_in + self.n_struct, packing.K_CHUNK)
+    if c_out > 240:
+      raise NotImplementedError("decoder width above 240 needs a wider output tile")
+    self._stream = None
+    self._keep = []            # keeps every tensor referenced by raw pointer alive
+    self._build(graphs, params)
+    self._programs: Dict[int, tuple] = {}
+
+  # ---------------------------------------------------------------- helpers
+  def _new(self, rows, cols=D):
+    t = torch.empty((rows, cols), dtype=torch.float32, device=self.dev)
+    self._keep.append(t)
+    return t
+
+  def _up(self, a, dtype=np.float32):
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).to(self.dev)
+    self._keep.append(t)
+    return t
+
+  def _stream_ptr(self):
+    return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+  @staticmethod
+  def _desc(mode, n_rows, *, a0=None, k0=0, lda0=None, a1=None, k1=0, lda1=None, w1p=None,
+            d=None, g0=None, idx0=None, g1=None, idx1=None, b1=None, w2p=None, b2=None, n2=0,
+            ln=None, res=None, out=None, ldo=None, out_ptr=None, edges: Optional[_Edges] = None,
+            agg=None):
+    ds = nat.RowMlpDesc()
+    ds.mode, ds.n_rows = mode, n_rows
+    ds.a0, ds.k0, ds.lda0 = nat.ptr(a0), k0, (lda0 if lda0 is not None else (a0.shape[1] if a0 is not None else 0))
+    ds.a1, ds.k1, ds.lda1 = nat.ptr(a1), k1, (lda1 if lda1 is not None else (a1.shape[1] if a1 is not None else 0))
+    ds.w1p = nat.ptr(w1p)
+    ds.d, ds.ldd = nat.ptr(d), (d.shape[1] if d is not None else 0)
+    ds.g0, ds.idx0, ds.g1, ds.idx1 = nat.ptr(g0), nat.ptr(idx0), nat.ptr(g1), nat.ptr(idx1)
+    ds.b1 = nat.ptr(b1)
+    ds.w2p, ds.b2, ds.n2 = nat.ptr(w2p), nat.ptr(b2), n2
+    if ln is not None:
+      ds.ln_scale, ds.ln_offset = nat.ptr(ln[0]), nat.ptr(ln[1])
+    ds.res, ds.ldres = nat.ptr(res), (res.shape[1] if res is not None else 0)
+    ds.out = out_ptr if out_ptr is not None else nat.ptr(out)
+    ds.ldo = ldo if ldo is not None else (out.shape[1] if out is not None else 0)
+    if edges is not None:
+      ds.seg, ds.tile_flags = nat.ptr(edges.rcv), nat.ptr(edges.flags)
+      ds.agg, ds.partial = nat.ptr(agg), nat.ptr(edges.partial)
+    return ds
+
+  def _op_mlp(self, tag, desc):
+    op = nat.Op()
+    op.kind, op.tag, op.mlp = nat.OP_ROWMLP, TAGS[tag], desc
+    return op
+
+  def _ops_after_segsum(self, edges: _Edges, agg):
+    ops = []
+    if edges.fix is not None:
+      op = nat.Op()
+      op.kind, op.tag, op.n = nat.OP_FIXUP, TAGS["fixup"], edges.fix[0].numel()
+      op.i0, op.i1, op.i2 = (nat.ptr(t) for t in edges.fix)
+      op.src, op.dst = nat.ptr(edges.partial), nat.ptr(agg)
+      ops.append(op)
+    if edges.empty is not None:
+      op = nat.Op()
+      op.kind, op.tag, op.n = nat.OP_ZERO, TAGS["fixup"], edges.empty.numel()
+      op.i0, op.dst = nat.ptr(edges.empty), nat.ptr(agg)
+      ops.append(op)
+    return ops
+
+  def _run(self, ops):
+    arr = (nat.Op * len(ops))(*ops)
+    nat.check(self.lib.gc_run_program(arr, len(ops), self._stream_ptr()), "gc_run_program")
+
+  def _mlp_ln(self, n_rows, mlp: _Mlp, **kw):
+    return self._desc(nat.MODE_MLP_LN, n_rows, w2p=mlp.w2, b2=mlp.b2, n2=D,
+                      ln=(mlp.scale, mlp.offset), **kw)
+
+  # ---------------------------------------------------------------- build
+  def _build(self, graphs, params):
+    dev = self.dev
+    G = "grid2mesh_gnn/~_networks_builder/"
+    M = "mesh_gnn/~_networks_builder/"
+    X = "mesh2grid_gnn/~_networks_builder/"
+    esr = ("e", "s", "r")
+    self.m_enc_grid = _Mlp(params, G + "encoder_nodes_grid_nodes", dev)
+    m_enc_mesh = _Mlp(params, G + "encoder_nodes_mesh_nodes", dev)
+    m_enc_e_g2m = _Mlp(params, G + "encoder_edges_grid2mesh", dev)
+    self.m_g2m_edge = _Mlp(params, G + "processor_edges_0_grid2mesh", dev, split=esr)
+    self.m_g2m_mesh = _Mlp(params, G + "processor_nodes_0_mesh_nodes", dev, split=("h", "a"))
+    self.m_g2m_grid = _Mlp(params, G + "processor_nodes_0_grid_nodes", dev)
+    m_enc_e_mesh = _Mlp(params, M + "encoder_edges_mesh", dev)
+    self.m_proc_edge = [_Mlp(params, M + f"processor_edges_{i}_mesh", dev, split=esr)
+                        for i in range(self.num_steps)]
+    self.m_proc_node = [_Mlp(params, M + f"processor_nodes_{i}_mesh_nodes", dev)
+                        for i in range(self.num_steps)]
+    m_enc_e_m2g = _Mlp(params, X + "encoder_edges_mesh2grid", dev)
+    self.m_m2g_edge = _Mlp(params, X + "processor_edges_0_mesh2grid", dev, split=esr)
+    self.m_m2g_grid = _Mlp(params, X + "processor_nodes_0_grid_nodes", dev)
+    self.m_out = _Mlp(params, X + "decoder_nodes_grid_nodes", dev, np2=256)
+    if self.m_out.n_out != self.c_out:
+      raise ValueError(f"decoder produces {self.m_out.n_out} channels, task needs {self.c_out}")
+    if self.m_enc_grid.k_in != self.c_in + self.n_struct:
+      raise ValueError(f"grid embedder expects {self.m_enc_grid.k_in} input channels, "
+                       f"got {self.c_in} + {self.n_struct} structural")
+    self._keep += [self.m_enc_grid, self.m_g2m_edge, self.m_g2m_mesh, self.m_g2m_grid,
+                   self.m_proc_edge, self.m_proc_node, self.m_m2g_edge, self.m_m2g_grid, self.m_out]
+
+    self.e_g2m = _Edges(packing.pack_edges(graphs["g2m"]["senders"], graphs["g2m"]["receivers"],
+                                           self.n_mesh), dev)
+    self.e_mesh = _Edges(packing.pack_edges(graphs["mesh"]["senders"], graphs["mesh"]["receivers"],
+                                            self.n_mesh), dev)
+    self.e_m2g = _Edges(packing.pack_edges(graphs["m2g"]["senders"], graphs["m2g"]["receivers"],
+                                           self.n_grid), dev)
+    self.grid_struct = self._up(graphs["grid_node_feat"])
+
+    # ---- load-time constant folding, on the device --------------------------
+    nm, ng = self.n_mesh, self.n_grid
+
+    def edge_feat_rows(edges: _Edges, feat):
+      rows = np.zeros((edges.n_rows, packing.K_CHUNK), dtype=np.float32)
+      ok = edges.pk.perm >= 0
+      rows[ok, :feat.shape[1]] = np.asarray(feat)[edges.pk.perm[ok]].astype(np.float32)
+      return torch.from_numpy(rows).to(dev)
+
+    def embed(mlp: _Mlp, rows_in):
+      out = torch.empty((rows_in.shape[0], D), dtype=torch.float32, device=dev)
+      self._run([self._op_mlp("enc_pre", self._mlp_ln(
+          rows_in.shape[0], mlp, a0=rows_in, k0=rows_in.shape[1], w1p=mlp.w1, b1=mlp.b1, out=out))])
+      return out
+
+    def linear(rows_in, wp, n_rows=None, **kw):
+      n_rows = rows_in.shape[0] if n_rows is None else n_rows
+      out = torch.empty((n_rows, D), dtype=torch.float32, device=dev)
+      self._run([self._op_mlp("enc_pre", self._desc(
+          nat.MODE_LINEAR, n_rows, a0=rows_in, k0=D, w1p=wp, out=out, **kw))])
+      return out
+
+    mesh_in = np.zeros((nm, self.kp), dtype=np.float32)
+    mesh_in[:, self.c_in:self.c_in + self.n_struct] = graphs["mesh_node_feat"]
+    self.h_mesh0 = embed(m_enc_mesh, torch.from_numpy(mesh_in).to(dev))            # [N_m, 512]
+    # grid2mesh edge first layer: e0.We + b1 + (h_mesh0.Wr)[receivers]   (per packed edge)
+    e0 = embed(m_enc_e_g2m, edge_feat_rows(self.e_g2m, graphs["g2m"]["feat"]))
+    pre_r = linear(self.h_mesh0, self.m_g2m_edge.w1["r"])
+    self.d_g2m = linear(e0, self.m_g2m_edge.w1["e"], b1=self.m_g2m_edge.b1, g1=pre_r,
+                        idx1=self.e_g2m.rcv)
+    del e0, pre_r
+    # encoder mesh-node update first layer: h_mesh0.Wh + b1
+    self.d_enc_mesh = linear(self.h_mesh0, self.m_g2m_mesh.w1["h"], b1=self.m_g2m_mesh.b1)
+    # multi-mesh: embedded edges (kept: residual of step 0) and step-0 first-layer edge term
+    self.e_mesh0 = embed(m_enc_e_mesh, edge_feat_rows(self.e_mesh, graphs["mesh"]["feat"]))
+    self.d_mesh0 = linear(self.e_mesh0, self.m_proc_edge[0].w1["e"], b1=self.m_proc_edge[0].b1)
+    # mesh2grid edge first layer: e0.We + b1
+    e0 = embed(m_enc_e_m2g, edge_feat_rows(self.e_m2g, graphs["m2g"]["feat"]))
+    self.d_m2g = linear(e0, self.m_m2g_edge.w1["e"], b1=self.m_m2g_edge.b1)
+    del e0
+    torch.cuda.synchronize(dev)
+    self._keep += [self.h_mesh0, self.d_g2m, self.d_enc_mesh, self.e_mesh0, self.d_mesh0, self.d_m2g,
+                   self.e_g2m, self.e_mesh, self.e_m2g]
+
+    # ---- per-step workspace ---------------------------------------------------
+    self.xin = self._new(ng, self.kp)
+    self.h_grid = self._new(ng)         # embedded grid latents, later reused for the decoder update
+    self.pre_grid = self._new(ng)       # h_grid.Ws (encoder) / h_grid2.Wr (decoder)
+    self.h_grid2 = self._new(ng)        # grid latents after the encoder's node update
+    self.agg_grid = self._new(ng)
+    self.h_mesh = self._new(nm)
+    self.agg_mesh = self._new(nm)
+    self.pre_s_mesh = self._new(nm)
+    self.pre_r_mesh = self._new(nm)
+    self.e_mesh_lat = self._new(self.e_mesh.n_rows)
+
+  # ---------------------------------------------------------------- program
+  def _program(self, batch):
+    """Op list for all batch elements; x / y pointers are patched per call."""
+    if batch in self._programs:
+      return self._programs[batch]
+    ng, nm = self.n_grid, self.n_mesh
+    ops, x_slots, y_slots = [], [], []
+    for b in range(batch):
+      op = nat.Op()
+      op.kind, op.tag, op.n = nat.OP_PREP, TAGS["prep"], ng
+      op.batch, op.b, op.c_in, op.n_struct, op.kp = batch, b, self.c_in, self.n_struct, self.kp
+      op.node_struct, op.dst = nat.ptr(self.grid_struct), nat.ptr(self.xin)
+      x_slots.append(len(ops))
+      ops.append(op)
+      # ---- encoder (grid2mesh GNN) ----
+      m = self.m_enc_grid
+      ops.append(self._op_mlp("enc_embed_grid", self._mlp_ln(
+          ng, m, a0=self.xin, k0=self.kp, w1p=m.w1, b1=m.b1, out=self.h_grid)))
+      m = self.m_g2m_edge
+      ops.append(self._op_mlp("enc_pre", self._desc(
+          nat.MODE_LINEAR, ng, a0=self.h_grid, k0=D, w1p=m.w1["s"], out=self.pre_grid)))
+      ops.append(self._op_mlp("enc_edge", self._mlp_ln(
+          self.e_g2m.n_rows, m, d=self.d_g2m, g0=self.pre_grid, idx0=self.e_g2m.snd,
+          edges=self.e_g2m, agg=self.agg_mesh)))
+      ops += self._ops_after_segsum(self.e_g2m, self.agg_mesh)
+      m = self.m_g2m_mesh
+      ops.append(self._op_mlp("enc_node_mesh", self._mlp_ln(
+          nm, m, a0=self.agg_mesh, k0=D, w1p=m.w1["a"], d=self.d_enc_mesh, res=self.h_mesh0,
+          out=self.h_mesh)))
+      m = self.m_g2m_grid
+      ops.append(self._op_mlp("enc_node_grid", self._mlp_ln(
+          ng, m, a0=self.h_grid, k0=D, w1p=m.w1, b1=m.b1, res=self.h_grid, out=self.h_grid2)))
+      # ---- processor (multi-mesh GNN) ----
+      for i in range(self.num_steps):
+        me, mn = self.m_proc_edge[i], self.m_proc_node[i]
+        last = i == self.num_steps - 1
+        ops.append(self._op_mlp("proc_pre", self._desc(
+            nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=me.w1["s"], out=self.pre_s_mesh)))
+        ops.append(self._op_mlp("proc_pre", self._desc(
+            nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=me.w1["r"], out=self.pre_r_mesh)))
+        common = dict(g0=self.pre_s_mesh, idx0=self.e_mesh.snd, g1=self.pre_r_mesh,
+                      idx1=self.e_mesh.rcv, edges=self.e_mesh, agg=self.agg_mesh)
+        if i == 0:
+          desc = self._mlp_ln(self.e_mesh.n_rows, me, d=self.d_mesh0, res=self.e_mesh0,
+                              out=None if last else self.e_mesh_lat, **common)
+          if last:
+            desc.res, desc.ldres = None, 0
+        else:
+          desc = self._mlp_ln(self.e_mesh.n_rows, me, a0=self.e_mesh_lat, k0=D, w1p=me.w1["e"],
+                              b1=me.b1, res=None if last else self.e_mesh_lat,
+                              out=None if last else self.e_mesh_lat, **common)
+        ops.append(self._op_mlp("proc_edge", desc))
+        ops += self._ops_after_segsum(self.e_mesh, self.agg_mesh)
+        ops.append(self._op_mlp("proc_node", self._mlp_ln(
+            nm, mn, a0=self.h_mesh, k0=D, a1=self.agg_mesh, k1=D, w1p=mn.w1, b1=mn.b1,
+            res=self.h_mesh, out=self.h_mesh)))
+      # ---- decoder (mesh2grid GNN) ----
+      m = self.m_m2g_edge
+      ops.append(self._op_mlp("dec_pre", self._desc(
+          nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=m.w1["s"], out=self.pre_s_mesh)))
+      ops.append(self._op_mlp("dec_pre", self._desc(
+          nat.MODE_LINEAR, ng, a0=self.h_grid2, k0=D, w1p=m.w1["r"], out=self.pre_grid)))
+      ops.append(self._op_mlp("dec_edge", self._mlp_ln(
+          self.e_m2g.n_rows, m, d=self.d_m2g, g0=self.pre_s_mesh, idx0=self.e_m2g.snd,
+          g1=self.pre_grid, idx1=self.e_m2g.rcv, edges=self.e_m2g, agg=self.agg_grid)))
+      ops += self._ops_after_segsum(self.e_m2g, self.agg_grid)
+      m = self.m_m2g_grid
+      ops.append(self._op_mlp("dec_node", self._mlp_ln(
+          ng, m, a0=self.h_grid2, k0=D, a1=self.agg_grid, k1=D, w1p=m.w1, b1=m.b1,
+          res=self.h_grid2, out=self.h_grid)))
+      m = self.m_out
+      y_slots.append(len(ops))
+      ops.append(self._op_mlp("dec_out", self._desc(
+          nat.MODE_MLP_OUT, ng, a0=self.h_grid, k0=D, w1p=m.w1, b1=m.b1, w2p=m.w2, b2=m.b2,
+          n2=self.c_out, out_ptr=0, ldo=batch * self.c_out)))
+    arr = (nat.Op * len(ops))(*ops)
+    self._programs[batch] = (arr, x_slots, y_slots)
+    return self._programs[batch]
+
+  def bind(self, x: torch.Tensor, y: Optional[torch.Tensor] = None):
+    """Validates x/y and returns (program array, y) with the x/y pointers patched in."""
+    if x.dtype != torch.float32 or x.dim() != 3 or not x.is_contiguous() or x.device != self.dev:
+      raise ValueError("x must be a contiguous float32 [N_grid, B, C_in] tensor on the engine's device")
+    if x.shape[0] != self.n_grid or x.shape[2] != self.c_in:
+      raise ValueError(f"x has shape {tuple(x.shape)}, expected [{self.n_grid}, B, {self.c_in}]")
+    batch = x.shape[1]
+    if y is None:
+      y = torch.empty((self.n_grid, batch, self.c_out), dtype=torch.float32, device=self.dev)
+    elif (y.shape != (self.n_grid, batch, self.c_out) or y.dtype != torch.float32
+          or not y.is_contiguous() or y.device != self.dev):
+      raise ValueError("y must be a contiguous float32 [N_grid, B, C_out] tensor on the engine's device")
+    arr, x_slots, y_slots = self._program(batch)
+    for b in range(batch):
+      arr[x_slots[b]].x = x.data_ptr()
+      arr[y_slots[b]].mlp.out = y.data_ptr() + 4 * b * self.c_out
+    return arr, y
+
+  def forward(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    arr, y = self.bind(x, y)
+    nat.check(self.lib.gc_run_program(arr, len(arr), self._stream_ptr()), "gc_run_program")
+    return y
+
+  __call__ = forward
+
+  def time_ops(self, x, iters=3):
+    """Per-op mean milliseconds measured with HIP events on the launch stream."""
+    arr, _ = self.bind(x)
+    ms = (ctypes.c_float * len(arr))()
+    nat.check(self.lib.gc_time_program(arr, len(arr), iters, ms, self._stream_ptr()),
+              "gc_time_program")
+    return [(arr[k].tag, arr[k].kind, ms[k]) for k in range(len(arr))]

@@ -1,0 +1,285 @@
+"""GraphCast Predictor on an MI355X: drop-in for the reference's
+``weathernext/weathernext1_graph/graphcast.py`` (same public names:
+``GraphCast``, ``ModelConfig``, ``TaskConfig``, ``CheckPoint``, ``TASK``,
+``TASK_13``, ``TASK_13_PRECIP_OUT``; same call signature and lazy,
+coordinate-driven graph initialisation, reference :184-292, :298-329, :368-548).
+
+The difference is what happens between ``_inputs_to_grid_node_features`` and
+``_grid_node_outputs_to_prediction`` (reference :309-323): instead of three
+haiku ``DeepTypedGraphNet``s traced by XLA, a ``StepEngine`` replays a fixed
+program of hand-written gfx950 kernels (engine.py, csrc/gcast.hip).
+
+Parameters are passed explicitly (``GraphCast(model_config, task_config,
+params=...)`` or ``load_params``) in the reference's haiku tree layout
+(``"<gnn>/~_networks_builder/<stem>_mlp/~/linear_<k>" -> {"w", "b"}``), i.e.
+exactly the ``params`` of a reference ``CheckPoint`` (:145-151).
+"""
+import dataclasses
+from typing import Any, Mapping, Optional
+
+import numpy as np
+
+from graphcast_amd import grid_mesh_connectivity
+from graphcast_amd import icosahedral_mesh
+from graphcast_amd import model_utils
+from graphcast_amd import predictor_base
+from graphcast_amd import typed_graph
+from graphcast_amd import variables
+
+PRESSURE_LEVELS = variables.PRESSURE_LEVELS
+
+TARGET_SURFACE_VARS = ("2m_temperature", "mean_sea_level_pressure", "10m_v_component_of_wind",
+                       "10m_u_component_of_wind", "total_precipitation_6hr")
+TARGET_SURFACE_NO_PRECIP_VARS = TARGET_SURFACE_VARS[:4]
+TARGET_ATMOSPHERIC_VARS = ("temperature", "geopotential", "u_component_of_wind",
+                           "v_component_of_wind", "vertical_velocity", "specific_humidity")
+TARGET_ATMOSPHERIC_NO_W_VARS = tuple(v for v in TARGET_ATMOSPHERIC_VARS if v != "vertical_velocity")
+FORCING_VARS = variables.EXTERNAL_FORCING_VARS + variables.TIME_FORCING_VARS
+
+
+@dataclasses.dataclass(frozen=True, eq=True)
+class TaskConfig:
+  """Inputs / targets of a task (reference ``utils/task.py:20-29``)."""
+  input_variables: tuple
+  target_variables: tuple
+  forcing_variables: tuple
+  pressure_levels: tuple
+  input_duration: str
+
+
+TASK = TaskConfig(
+    input_variables=TARGET_SURFACE_VARS + TARGET_ATMOSPHERIC_VARS + FORCING_VARS + variables.STATIC_VARS,
+    target_variables=TARGET_SURFACE_VARS + TARGET_ATMOSPHERIC_VARS,
+    forcing_variables=FORCING_VARS,
+    pressure_levels=variables.PRESSURE_LEVELS_ERA5_37,
+    input_duration="12h")
+TASK_13 = dataclasses.replace(TASK, pressure_levels=variables.PRESSURE_LEVELS_WEATHERBENCH_13)
+TASK_13_PRECIP_OUT = dataclasses.replace(
+    TASK_13,
+    input_variables=(TARGET_SURFACE_NO_PRECIP_VARS + TARGET_ATMOSPHERIC_VARS + FORCING_VARS
+                     + variables.STATIC_VARS))
+
+
+@dataclasses.dataclass(frozen=True, eq=True)
+class ModelConfig:
+  """Architecture hyper-parameters (reference :115-142, same field names)."""
+  resolution: float
+  mesh_size: int
+  latent_size: int
+  gnn_msg_steps: int
+  hidden_layers: int
+  radius_query_fraction_edge_length: float
+  mesh2grid_edge_normalization_factor: Optional[float] = None
+
+
+@dataclasses.dataclass(frozen=True, eq=True)
+class CheckPoint:
+  params: dict
+  model_config: ModelConfig
+  task_config: TaskConfig
+  description: str
+  license: str
+
+
+def num_output_channels(task_config: TaskConfig) -> int:
+  """reference :236-241."""
+  targets = set(task_config.target_variables)
+  n_atmos = len(targets & set(variables.ALL_ATMOSPHERIC_VARS))
+  return len(targets) - n_atmos + len(task_config.pressure_levels) * n_atmos
+
+
+def _get_max_edge_distance(mesh):
+  senders, receivers = icosahedral_mesh.faces_to_edges(mesh.faces)
+  return np.linalg.norm(mesh.vertices[senders] - mesh.vertices[receivers], axis=-1).max()
+
+
+class GraphCast(predictor_base.Predictor):
+  """GraphCast Predictor (Grid2Mesh encoder, multi-mesh processor, Mesh2Grid decoder)."""
+
+  def __init__(self, model_config: ModelConfig, task_config: TaskConfig,
+               params: Optional[Mapping[str, Mapping[str, Any]]] = None, device: str = "cuda:0"):
+    if model_config.hidden_layers != 1:
+      raise NotImplementedError("the MI355X build fuses exactly one hidden layer per MLP "
+                                "(hidden_layers=1, the value of every published GraphCast)")
+    if model_config.latent_size != 512:
+      raise NotImplementedError("the MI355X kernels are built for latent_size=512")
+    self._model_config = model_config
+    self._task_config = task_config
+    self._device = device
+    self._spatial_features_kwargs = dict(
+        add_node_positions=False, add_node_latitude=True, add_node_longitude=True,
+        add_relative_positions=True, relative_longitude_local_coordinates=True,
+        relative_latitude_local_coordinates=True)
+    self._meshes = icosahedral_mesh.get_hierarchy_of_triangular_meshes_for_sphere(
+        splits=model_config.mesh_size)
+    self._num_outputs = num_output_channels(task_config)
+    self._query_radius = (_get_max_edge_distance(self._finest_mesh)
+                          * model_config.radius_query_fraction_edge_length)
+    self._mesh2grid_edge_normalization_factor = model_config.mesh2grid_edge_normalization_factor
+    self._params = params
+    self._initialized = False
+    self._engine = None
+    self._grid2mesh_graph_structure = None
+    self._mesh_graph_structure = None
+    self._mesh2grid_graph_structure = None
+
+  # ---------------------------------------------------------------- params
+  def load_params(self, params: Mapping[str, Mapping[str, Any]]) -> None:
+    self._params = params
+    self._engine = None
+
+  @property
+  def _finest_mesh(self):
+    return self._meshes[-1]
+
+  # ---------------------------------------------------------------- static graphs
+  def _maybe_init(self, grid_lat: np.ndarray, grid_lon: np.ndarray):
+    """Everything that depends on the input coordinates (reference :368-378)."""
+    if not self._initialized:
+      self._init_mesh_properties()
+      self._init_grid_properties(grid_lat=np.asarray(grid_lat), grid_lon=np.asarray(grid_lon))
+      self._grid2mesh_graph_structure = self._init_grid2mesh_graph()
+      self._mesh_graph_structure = self._init_mesh_graph()
+      self._mesh2grid_graph_structure = self._init_mesh2grid_graph()
+      self._initialized = True
+
+  def _init_mesh_properties(self):
+    v = self._finest_mesh.vertices
+    self._num_mesh_nodes = v.shape[0]
+    phi, theta = model_utils.cartesian_to_spherical(v[:, 0], v[:, 1], v[:, 2])
+    lat, lon = model_utils.spherical_to_lat_lon(phi=phi, theta=theta)
+    self._mesh_nodes_lat = lat.astype(np.float32)
+    self._mesh_nodes_lon = lon.astype(np.float32)
+
+  def _init_grid_properties(self, grid_lat: np.ndarray, grid_lon: np.ndarray):
+    self._grid_lat = grid_lat.astype(np.float32)
+    self._grid_lon = grid_lon.astype(np.float32)
+    self._num_grid_nodes = grid_lat.shape[0] * grid_lon.shape[0]
+    lon2d, lat2d = np.meshgrid(grid_lon, grid_lat)       # node id = i_lat * n_lon + i_lon
+    self._grid_nodes_lon = lon2d.reshape([-1]).astype(np.float32)
+    self._grid_nodes_lat = lat2d.reshape([-1]).astype(np.float32)
+
+  def _bipartite_graph(self, name, sender_set, receiver_set, senders, receivers, s_feat, r_feat,
+                       e_feat):
+    nodes = {
+        sender_set: typed_graph.NodeSet(n_node=np.array([s_feat.shape[0]]), features=s_feat),
+        receiver_set: typed_graph.NodeSet(n_node=np.array([r_feat.shape[0]]), features=r_feat)}
+    # the reference always lists grid_nodes first
+    nodes = {k: nodes[k] for k in ("grid_nodes", "mesh_nodes")}
+    edge_set = typed_graph.EdgeSet(
+        n_edge=np.array([senders.shape[0]]),
+        indices=typed_graph.EdgesIndices(senders=senders, receivers=receivers), features=e_feat)
+    return typed_graph.TypedGraph(
+        context=typed_graph.Context(n_graph=np.array([1]), features=()), nodes=nodes,
+        edges={typed_graph.EdgeSetKey(name, (sender_set, receiver_set)): edge_set})
+
+  def _init_grid2mesh_graph(self) -> typed_graph.TypedGraph:
+    grid_indices, mesh_indices = grid_mesh_connectivity.radius_query_indices(
+        grid_latitude=self._grid_lat, grid_longitude=self._grid_lon, mesh=self._finest_mesh,
+        radius=self._query_radius)
+    s_feat, r_feat, e_feat = model_utils.get_bipartite_graph_spatial_features(
+        senders_node_lat=self._grid_nodes_lat, senders_node_lon=self._grid_nodes_lon,
+        receivers_node_lat=self._mesh_nodes_lat, receivers_node_lon=self._mesh_nodes_lon,
+        senders=grid_indices, receivers=mesh_indices, edge_normalization_factor=None,
+        **self._spatial_features_kwargs)
+    return self._bipartite_graph("grid2mesh", "grid_nodes", "mesh_nodes", grid_indices,
+                                 mesh_indices, s_feat, r_feat, e_feat)
+
+  def _init_mesh_graph(self) -> typed_graph.TypedGraph:
+    merged = icosahedral_mesh.merge_meshes(self._meshes)
+    senders, receivers = icosahedral_mesh.faces_to_edges(merged.faces)
+    node_feat, edge_feat = model_utils.get_graph_spatial_features(
+        node_lat=self._mesh_nodes_lat, node_lon=self._mesh_nodes_lon, senders=senders,
+        receivers=receivers, **self._spatial_features_kwargs)
+    assert self._num_mesh_nodes == len(node_feat)
+    return typed_graph.TypedGraph(
+        context=typed_graph.Context(n_graph=np.array([1]), features=()),
+        nodes={"mesh_nodes": typed_graph.NodeSet(n_node=np.array([self._num_mesh_nodes]),
+                                                 features=node_feat)},
+        edges={typed_graph.EdgeSetKey("mesh", ("mesh_nodes", "mesh_nodes")): typed_graph.EdgeSet(
+            n_edge=np.array([senders.shape[0]]),
+            indices=typed_graph.EdgesIndices(senders=senders, receivers=receivers),
+            features=edge_feat)})
+
+  def _init_mesh2grid_graph(self) -> typed_graph.TypedGraph:
+    grid_indices, mesh_indices = grid_mesh_connectivity.in_mesh_triangle_indices(
+        grid_latitude=self._grid_lat, grid_longitude=self._grid_lon, mesh=self._finest_mesh)
+    s_feat, r_feat, e_feat = model_utils.get_bipartite_graph_spatial_features(
+        senders_node_lat=self._mesh_nodes_lat, senders_node_lon=self._mesh_nodes_lon,
+        receivers_node_lat=self._grid_nodes_lat, receivers_node_lon=self._grid_nodes_lon,
+        senders=mesh_indices, receivers=grid_indices,
+        edge_normalization_factor=self._mesh2grid_edge_normalization_factor,
+        **self._spatial_features_kwargs)
+    return self._bipartite_graph("mesh2grid", "mesh_nodes", "grid_nodes", mesh_indices,
+                                 grid_indices, s_feat, r_feat, e_feat)
+
+  def graph_arrays(self) -> dict:
+    """The static structure as plain arrays (what StepEngine consumes)."""
+    assert self._initialized
+    g2m = self._grid2mesh_graph_structure.edge_by_name("grid2mesh")
+    mesh = self._mesh_graph_structure.edge_by_name("mesh")
+    m2g = self._mesh2grid_graph_structure.edge_by_name("mesh2grid")
+    pick = lambda e: dict(senders=e.indices.senders, receivers=e.indices.receivers, feat=e.features)
+    return dict(
+        n_grid=self._num_grid_nodes, n_mesh=self._num_mesh_nodes, radius=self._query_radius,
+        grid_node_feat=self._grid2mesh_graph_structure.nodes["grid_nodes"].features,
+        mesh_node_feat=self._grid2mesh_graph_structure.nodes["mesh_nodes"].features,
+        g2m=pick(g2m), mesh=pick(mesh), m2g=pick(m2g))
+
+  # ---------------------------------------------------------------- tensor boundary
+  def _get_engine(self, c_in):
+    if self._engine is None:
+      if self._params is None:
+        raise ValueError("GraphCast has no parameters: pass params= or call load_params()")
+      from graphcast_amd import engine      # needs the HIP library; fails loudly without it
+      self._engine = engine.StepEngine(
+          self.graph_arrays(), self._params, num_steps=self._model_config.gnn_msg_steps,
+          c_in=c_in, c_out=self._num_outputs, device=self._device)
+    return self._engine
+
+  def forward_grid_node_features(self, grid_node_features, out=None):
+    """[N_grid, B, C_in] float32 device tensor -> [N_grid, B, C_out] (reference :311-323).
+
+    ``_maybe_init`` must have run (``init_from_coordinates`` or a Dataset call)."""
+    if not self._initialized:
+      raise ValueError("static graphs are not initialised; call init_from_coordinates(lat, lon)")
+    return self._get_engine(grid_node_features.shape[-1])(grid_node_features, out)
+
+  def init_from_coordinates(self, lat, lon):
+    self._maybe_init(lat, lon)
+    return self
+
+  # ---------------------------------------------------------------- Dataset boundary
+  def __call__(self, inputs, targets_template, forcings, is_training: bool = False):
+    from graphcast_amd import xarray_lite as xl
+    import torch
+    self._maybe_init(np.asarray(inputs.coords["lat"]), np.asarray(inputs.coords["lon"]))
+    features = self._inputs_to_grid_node_features(inputs, forcings)
+    x = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(self._device)
+    y = self.forward_grid_node_features(x)
+    return self._grid_node_outputs_to_prediction(y.cpu().numpy(), targets_template)
+
+  def _inputs_to_grid_node_features(self, inputs, forcings) -> np.ndarray:
+    """Datasets -> [num_grid_nodes, batch, num_channels] (reference :680-699)."""
+    from graphcast_amd import xarray_lite as xl
+    stacked_inputs = model_utils.dataset_to_stacked(inputs)
+    stacked_forcings = model_utils.dataset_to_stacked(forcings)
+    stacked = xl.concat([stacked_inputs, stacked_forcings], dim="channels")
+    leading = model_utils.lat_lon_to_leading_axes(stacked)
+    data = np.asarray(leading.data)
+    return data.reshape((-1,) + data.shape[2:])
+
+  def _grid_node_outputs_to_prediction(self, grid_node_outputs: np.ndarray, targets_template):
+    """[num_grid_nodes, batch, num_outputs] -> Dataset (reference :701-723)."""
+    from graphcast_amd import xarray_lite as xl
+    grid_shape = (self._grid_lat.shape[0], self._grid_lon.shape[0])
+    leading = xl.DataArray(grid_node_outputs.reshape(grid_shape + grid_node_outputs.shape[1:]),
+                           dims=("lat", "lon", "batch", "channels"))
+    restored = model_utils.restore_leading_axes(leading)
+    return model_utils.stacked_to_dataset(restored.variable, targets_template)
+
+  def loss_and_predictions(self, inputs, targets, forcings):
+    raise NotImplementedError("inference build: training losses (reference :331-357) are out of scope")
+
+  def loss(self, inputs, targets, forcings):
+    raise NotImplementedError("inference build: training losses (reference :359-366) are out of scope")

@@ -1,0 +1,110 @@
+"""Grid <-> mesh edge index builders (host side, runs once per Predictor).
+
+Same names / argument meaning / results as the reference's
+``weathernext/utils/legacy/grid_mesh_connectivity.py``:
+``radius_query_indices`` (:40-86) and ``in_mesh_triangle_indices`` (:89-134).
+
+* The radius query uses the same scipy cKDTree ball query as the reference (so
+  the ``<= radius`` boundary is decided by the same code), flattened without the
+  per-point Python loop.
+* The containing-triangle query does not need trimesh/rtree: candidate faces
+  come from a KD-tree over face centroids, the exact decision rule is
+  trimesh's (closest point on each candidate triangle, minimum distance, ties
+  within 1e-8 broken by alignment with the face normal, then lowest face id).
+"""
+from typing import Tuple
+
+import numpy as np
+import scipy.spatial
+
+from graphcast_amd import icosahedral_mesh
+
+_TIE_TOLERANCE = 1e-8     # trimesh tol.merge
+_NUM_CANDIDATE_FACES = 8
+
+
+def _grid_lat_lon_to_coordinates(grid_latitude: np.ndarray,
+                                 grid_longitude: np.ndarray) -> np.ndarray:
+  """Lat [num_lat], lon [num_lon] (degrees) -> unit vectors [num_lat, num_lon, 3]."""
+  phi = np.deg2rad(grid_longitude)[None, :]
+  theta = np.deg2rad(90 - grid_latitude)[:, None]
+  sin_theta = np.sin(theta)
+  return np.stack([np.cos(phi) * sin_theta, np.sin(phi) * sin_theta,
+                   np.cos(theta) * np.ones_like(phi)], axis=-1)
+
+
+def radius_query_indices(*, grid_latitude: np.ndarray, grid_longitude: np.ndarray,
+                         mesh: icosahedral_mesh.TriangularMesh,
+                         radius: float) -> Tuple[np.ndarray, np.ndarray]:
+  """Edges (grid point -> mesh vertex) with chord distance <= radius, grid-major."""
+  grid_positions = _grid_lat_lon_to_coordinates(grid_latitude, grid_longitude).reshape([-1, 3])
+  tree = scipy.spatial.cKDTree(mesh.vertices)
+  neighbours = tree.query_ball_point(x=grid_positions, r=radius)
+  counts = np.fromiter((len(n) for n in neighbours), dtype=np.int64, count=len(neighbours))
+  grid_edge_indices = np.repeat(np.arange(len(neighbours)), counts).astype(int)
+  mesh_edge_indices = np.fromiter(
+      (m for n in neighbours for m in n), dtype=np.int64, count=int(counts.sum())).astype(int)
+  return grid_edge_indices, mesh_edge_indices
+
+
+def _closest_points_on_triangles(p, a, b, c):
+  """Vectorised closest point on triangle (Voronoi-region classification)."""
+  ab, ac = b - a, c - a
+  dot = lambda u, v: np.einsum("ij,ij->i", u, v)
+  d1, d2 = dot(ab, p - a), dot(ac, p - a)
+  d3, d4 = dot(ab, p - b), dot(ac, p - b)
+  d5, d6 = dot(ab, p - c), dot(ac, p - c)
+  va, vb, vc = d3 * d6 - d5 * d4, d5 * d2 - d1 * d6, d1 * d4 - d3 * d2
+  with np.errstate(divide="ignore", invalid="ignore"):
+    t_ab = d1 / (d1 - d3)
+    t_ac = d2 / (d2 - d6)
+    t_bc = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+    inv = 1.0 / (va + vb + vc)
+  conditions = [
+      (d1 <= 0) & (d2 <= 0),
+      (d3 >= 0) & (d4 <= d3),
+      (vc <= 0) & (d1 >= 0) & (d3 <= 0),
+      (d6 >= 0) & (d5 <= d6),
+      (vb <= 0) & (d2 >= 0) & (d6 <= 0),
+      (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0),
+  ]
+  choices = [a, b, a + t_ab[:, None] * ab, c, a + t_ac[:, None] * ac, b + t_bc[:, None] * (c - b)]
+  interior = a + ab * (vb * inv)[:, None] + ac * (vc * inv)[:, None]
+  region = np.select(conditions, np.arange(6), default=6)
+  out = interior
+  for k, choice in enumerate(choices):
+    out = np.where((region == k)[:, None], choice, out)
+  return out
+
+
+def _nearest_face_on_surface(points: np.ndarray, mesh: icosahedral_mesh.TriangularMesh) -> np.ndarray:
+  vertices = mesh.vertices.astype(np.float64)
+  faces = mesh.faces
+  points = points.astype(np.float64)
+  corners = vertices[faces]                                     # [F, 3, 3]
+  normals = np.cross(corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 0])
+  normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+  k = min(_NUM_CANDIDATE_FACES, len(faces))
+  _, candidates = scipy.spatial.cKDTree(corners.mean(axis=1)).query(points, k=k)
+  candidates = np.sort(candidates.reshape(len(points), k), axis=1)   # ascending face id
+  distance = np.empty(candidates.shape)
+  alignment = np.empty(candidates.shape)
+  for j in range(k):
+    f = candidates[:, j]
+    q = _closest_points_on_triangles(points, corners[f, 0], corners[f, 1], corners[f, 2])
+    delta = points - q
+    distance[:, j] = np.linalg.norm(delta, axis=1)
+    alignment[:, j] = np.abs(np.einsum("ij,ij->i", normals[f], delta))
+  tied = distance <= distance.min(axis=1, keepdims=True) + _TIE_TOLERANCE
+  pick = np.argmax(np.where(tied, alignment, -np.inf), axis=1)
+  return candidates[np.arange(len(points)), pick]
+
+
+def in_mesh_triangle_indices(*, grid_latitude: np.ndarray, grid_longitude: np.ndarray,
+                             mesh: icosahedral_mesh.TriangularMesh) -> Tuple[np.ndarray, np.ndarray]:
+  """3 edges per grid point: the vertices of the mesh face nearest to it -> that grid point."""
+  grid_positions = _grid_lat_lon_to_coordinates(grid_latitude, grid_longitude).reshape([-1, 3])
+  query_face_indices = _nearest_face_on_surface(grid_positions, mesh)
+  mesh_edge_indices = mesh.faces[query_face_indices].reshape([-1])
+  grid_edge_indices = np.repeat(np.arange(grid_positions.shape[0]), 3)
+  return grid_edge_indices, mesh_edge_indices

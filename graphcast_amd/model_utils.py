@@ -1,0 +1,136 @@
+"""Structural (lat/lon-derived) node and edge features + Dataset <-> [node, batch, channel] stacking.
+
+Host side.  Same public names, argument meaning and results as the parts of the
+reference's ``weathernext/utils/model_utils.py`` that GraphCast uses
+(``get_graph_spatial_features`` :29-152, ``get_bipartite_graph_spatial_features``
+:406-544, the spherical helpers :180-234, the stacking helpers :155-177,645-776).
+The receiver-local rotation is written in closed form (R = Ry(pi/2 - theta) .
+Rz(-phi)) instead of going through scipy Rotation objects and per-edge 3x3
+matrix gathers: only the rotated difference is ever formed.
+"""
+from typing import Mapping, Optional, Tuple
+
+import numpy as np
+
+
+def lat_lon_deg_to_spherical(node_lat, node_lon):
+  return np.deg2rad(node_lon), np.deg2rad(90 - node_lat)
+
+
+def spherical_to_lat_lon(phi, theta):
+  return 90 - np.rad2deg(theta), np.mod(np.rad2deg(phi), 360)
+
+
+def cartesian_to_spherical(x, y, z):
+  with np.errstate(invalid="ignore"):
+    return np.arctan2(y, x), np.arccos(z)
+
+
+def spherical_to_cartesian(phi, theta):
+  return np.cos(phi) * np.sin(theta), np.sin(phi) * np.sin(theta), np.cos(theta)
+
+
+def lat_lon_to_cartesian(lat, lon):
+  return spherical_to_cartesian(*lat_lon_deg_to_spherical(lat, lon))
+
+
+def cartesian_to_lat_lon(x, y, z):
+  return spherical_to_lat_lon(*cartesian_to_spherical(x, y, z))
+
+
+def _node_features(phi, theta, num_nodes, dtype, add_node_positions, add_node_latitude,
+                   add_node_longitude):
+  feats = []
+  if add_node_positions:
+    feats.extend(spherical_to_cartesian(phi, theta))
+  if add_node_latitude:
+    feats.append(np.cos(theta))
+  if add_node_longitude:
+    feats.append(np.cos(phi))
+    feats.append(np.sin(phi))
+  if not feats:
+    return np.zeros([num_nodes, 0], dtype=dtype)
+  return np.stack(feats, axis=-1)
+
+
+def _relative_positions(s_phi, s_theta, r_phi, r_theta, senders, receivers,
+                        latitude_local_coordinates, longitude_local_coordinates):
+  """sender - receiver position in the receiver's rotated frame, float64 [E, 3]."""
+  s_pos = np.stack(spherical_to_cartesian(s_phi, s_theta), axis=-1)
+  r_pos = np.stack(spherical_to_cartesian(r_phi, r_theta), axis=-1)
+  if not (latitude_local_coordinates or longitude_local_coordinates):
+    return s_pos[senders] - r_pos[receivers]
+  # Rotation angles keep the reference's dtype path: computed in the node dtype,
+  # then promoted (scipy promotes euler angles to float64).
+  azimuth = (-r_phi).astype(np.float64)[receivers]
+  polar = (-r_theta + np.pi / 2).astype(np.float64)[receivers]
+  ca, sa = np.cos(azimuth), np.sin(azimuth)
+  cp, sp = np.cos(polar), np.sin(polar)
+
+  def rot_z(p, c, s):       # Rz(angle) p
+    return np.stack([c * p[:, 0] - s * p[:, 1], s * p[:, 0] + c * p[:, 1], p[:, 2]], axis=-1)
+
+  def rot_y(p, c, s):       # Ry(angle) p
+    return np.stack([c * p[:, 0] + s * p[:, 2], p[:, 1], -s * p[:, 0] + c * p[:, 2]], axis=-1)
+
+  def to_local(p):
+    p = p.astype(np.float64)
+    if longitude_local_coordinates and latitude_local_coordinates:
+      return rot_y(rot_z(p, ca, sa), cp, sp)
+    if longitude_local_coordinates:
+      return rot_z(p, ca, sa)
+    # latitude only: to longitude 0, polar rotation, back to the original longitude
+    return rot_z(rot_y(rot_z(p, ca, sa), cp, sp), ca, -sa)
+
+  return to_local(s_pos[senders]) - to_local(r_pos[receivers])
+
+
+def _edge_features(relative_position, num_edges, dtype, edge_normalization_factor):
+  distances = np.linalg.norm(relative_position, axis=-1, keepdims=True)
+  if edge_normalization_factor is None:
+    edge_normalization_factor = distances.max()
+  return np.concatenate([distances / edge_normalization_factor,
+                         relative_position / edge_normalization_factor], axis=-1)
+
+
+def get_graph_spatial_features(
+    *, node_lat: np.ndarray, node_lon: np.ndarray, senders: np.ndarray, receivers: np.ndarray,
+    add_node_positions: bool, add_node_latitude: bool, add_node_longitude: bool,
+    add_relative_positions: bool, edge_normalization_factor: Optional[float] = None,
+    relative_longitude_local_coordinates: bool, relative_latitude_local_coordinates: bool,
+    ) -> Tuple[np.ndarray, np.ndarray]:
+  """Node features [N, F_n] (node dtype) and edge features [E, F_e] (float64)."""
+  s_feat, _, e_feat = get_bipartite_graph_spatial_features(
+      senders_node_lat=node_lat, senders_node_lon=node_lon, senders=senders,
+      receivers_node_lat=node_lat, receivers_node_lon=node_lon, receivers=receivers,
+      add_node_positions=add_node_positions, add_node_latitude=add_node_latitude,
+      add_node_longitude=add_node_longitude, add_relative_positions=add_relative_positions,
+      edge_normalization_factor=edge_normalization_factor,
+      relative_longitude_local_coordinates=relative_longitude_local_coordinates,
+      relative_latitude_local_coordinates=relative_latitude_local_coordinates)
+  return s_feat, e_feat
+
+
+def get_bipartite_graph_spatial_features(
+    *, senders_node_lat: np.ndarray, senders_node_lon: np.ndarray, senders: np.ndarray,
+    receivers_node_lat: np.ndarray, receivers_node_lon: np.ndarray, receivers: np.ndarray,
+    add_node_positions: bool, add_node_latitude: bool, add_node_longitude: bool,
+    add_relative_positions: bool, edge_normalization_factor: Optional[float] = None,
+    relative_longitude_local_coordinates: bool, relative_latitude_local_coordinates: bool,
+    ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+  """(sender node features, receiver node features, edge features)."""
+  dtype = senders_node_lat.dtype
+  assert receivers_node_lat.dtype == dtype
+  s_phi, s_theta = lat_lon_deg_to_spherical(senders_node_lat, senders_node_lon)
+  r_phi, r_theta = lat_lon_deg_to_spherical(receivers_node_lat, receivers_node_lon)
+  flags = (add_node_positions, add_node_latitude, add_node_longitude)
+  s_feat = _node_features(s_phi, s_theta, senders_node_lat.shape[0], dtype, *flags)
+  r_feat = _node_features(r_phi, r_theta, receivers_node_lat.shape[0], dtype, *flags)
+  if add_relative_positions:
+    rel = _relative_positions(s_phi, s_theta, r_phi, r_theta, senders, receivers,
+                              relative_latitude_local_coordinates,
+                              relative_longitude_local_coordinates)
+    e_feat = _edge_features(rel, senders.shape[0], dtype, edge_normalization_factor)
+  else:
+    e_feat = np.zeros([senders.shape[0], 0], dtype=dtype)
+  return s_feat, r_feat, e_feat

@@ -1,0 +1,131 @@
+"""Host-side layout transforms for the device plan (pure numpy, CPU-testable).
+
+* ``pack_weight``: haiku ``w`` [K, N] -> the k4-interleaved layout the kernels
+  stream through LDS (see include/gcast.h).
+* ``pack_edges``: reorders an edge set into receiver-sorted rows packed into
+  64-row tiles, with the metadata the fused edge kernel needs to perform
+  ``jraph.segment_sum`` (reference ``typed_graph_net.py:532-538``)
+  deterministically: per-row receiver ids, per-tile straddle flags and the list
+  of receivers whose edges span more than one tile.
+
+The reference keeps edges in construction order (sender-sorted for grid2mesh,
+unsorted for the multi-mesh, receiver-sorted for mesh2grid,
+``SURVEY.md`` appendix A.1) and lets XLA scatter-add.  Edge latents are internal
+to the step, so the engine is free to keep them in packed order; ``perm``
+records packed row -> original edge id so that indices stay checkable
+bit-for-bit against the reference's.
+"""
+from typing import NamedTuple
+
+import numpy as np
+
+TILE = 64
+K_CHUNK = 32
+LATENT = 512
+
+
+def round_up(x, m):
+  return (x + m - 1) // m * m
+
+
+def pack_weight(w, np_cols=LATENT):
+  """[K, N] -> [ceil32(K)/4, np_cols, 4] float32 with Wp[q, n, j] = w[4q + j, n]."""
+  w = np.asarray(w, dtype=np.float32)
+  k, n = w.shape
+  if n > np_cols:
+    raise ValueError(f"weight has {n} columns, packed layout holds {np_cols}")
+  kp = round_up(k, K_CHUNK)
+  padded = np.zeros((kp, np_cols), dtype=np.float32)
+  padded[:k, :n] = w
+  return np.ascontiguousarray(padded.reshape(kp // 4, 4, np_cols).transpose(0, 2, 1))
+
+
+def unpack_weight(wp, k, n):
+  """Inverse of pack_weight (tests)."""
+  q, np_cols, _ = wp.shape
+  return wp.transpose(0, 2, 1).reshape(q * 4, np_cols)[:k, :n]
+
+
+def pad_vector(v, n=LATENT):
+  out = np.zeros(n, dtype=np.float32)
+  out[:len(v)] = v
+  return out
+
+
+class PackedEdges(NamedTuple):
+  n_edges: int              # real edges
+  n_rows: int               # packed rows (multiple of 64)
+  perm: np.ndarray          # [n_rows] int64: original edge id per packed row, -1 = padding
+  senders: np.ndarray       # [n_rows] int32, -1 = padding
+  receivers: np.ndarray     # [n_rows] int32, -1 = padding  (the kernel's `seg`)
+  tile_flags: np.ndarray    # [n_rows/64] int32, bit0/bit1 = first/last run straddles
+  fix_recv: np.ndarray      # [n_fix] int32 receivers spanning several tiles
+  fix_t0: np.ndarray        # [n_fix] int32 first tile
+  fix_t1: np.ndarray        # [n_fix] int32 last tile
+  empty_receivers: np.ndarray   # [n_empty] int32 receivers with no incoming edge
+
+
+def pack_edges(senders, receivers, n_receivers):
+  """Receiver-sorted (stable), tile-packed edge order + segment-sum metadata."""
+  senders = np.asarray(senders)
+  receivers = np.asarray(receivers)
+  n_edges = len(receivers)
+  if n_edges == 0:
+    raise ValueError("empty edge set")
+  if receivers.min() < 0 or receivers.max() >= n_receivers:
+    raise ValueError("receiver index out of range")
+  order = np.argsort(receivers, kind="stable")
+  r_sorted = receivers[order]
+  degree = np.bincount(r_sorted, minlength=n_receivers)
+  nonzero = degree[degree > 0]
+  uniform = int(nonzero[0]) if (nonzero == nonzero[0]).all() else 0
+
+  if uniform and uniform <= TILE and TILE % uniform:
+    # whole segments per tile, the tail rows of each tile are padding: no straddling
+    rows_per_tile = TILE // uniform * uniform
+    e = np.arange(n_edges)
+    pos = e // rows_per_tile * TILE + e % rows_per_tile
+    n_rows = round_up(int(pos[-1]) + 1, TILE)
+  else:
+    pos = np.arange(n_edges)
+    n_rows = round_up(n_edges, TILE)
+
+  perm = np.full(n_rows, -1, dtype=np.int64)
+  perm[pos] = order
+  snd = np.full(n_rows, -1, dtype=np.int32)
+  rcv = np.full(n_rows, -1, dtype=np.int32)
+  snd[pos] = senders[order]
+  rcv[pos] = r_sorted
+
+  n_tiles = n_rows // TILE
+  rt = rcv.reshape(n_tiles, TILE)
+  first = rt[:, 0]
+  # last valid receiver of every tile (padding only ever trails a tile)
+  n_valid = (rt >= 0).sum(axis=1)
+  last = rt[np.arange(n_tiles), np.maximum(n_valid - 1, 0)]
+  full = n_valid == TILE
+  cont = np.zeros(n_tiles, dtype=bool)            # tile t continues tile t-1's last run
+  cont[1:] = full[:-1] & (first[1:] == last[:-1]) & (first[1:] >= 0)
+  flags = cont.astype(np.int32)
+  flags[:-1] |= cont[1:].astype(np.int32) << 1
+
+  # receivers whose packed rows span more than one tile
+  seg_start = np.flatnonzero(np.r_[True, r_sorted[1:] != r_sorted[:-1]])
+  seg_end = np.r_[seg_start[1:], n_edges] - 1
+  t0 = pos[seg_start] // TILE
+  t1 = pos[seg_end] // TILE
+  span = t1 > t0
+  return PackedEdges(
+      n_edges=n_edges, n_rows=n_rows, perm=perm, senders=snd, receivers=rcv,
+      tile_flags=flags,
+      fix_recv=r_sorted[seg_start][span].astype(np.int32),
+      fix_t0=t0[span].astype(np.int32), fix_t1=t1[span].astype(np.int32),
+      empty_receivers=np.flatnonzero(degree == 0).astype(np.int32))
+
+
+def segment_sum_packed_reference(rows, packed: PackedEdges, n_receivers):
+  """What the device pipeline (tile kernel + fixup + zero rows) must produce (tests)."""
+  out = np.zeros((n_receivers, rows.shape[1]), dtype=rows.dtype)
+  ok = packed.receivers >= 0
+  np.add.at(out, packed.receivers[ok], rows[ok])
+  return out

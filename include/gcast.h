@@ -1,0 +1,154 @@
+/* gcast.h -- C-ABI of libgcast_hip.so: the MI355X (gfx950) device side of
+ * GraphCast's encode-process-decode step.
+ *
+ * The reference (google-deepmind/graphcast, packaged as `weathernext`) has no
+ * FFI: the path is Python calling jax/haiku/jraph.  Each entry point below
+ * replaces the XLA-lowered form of the reference interface cited next to it
+ * (paths relative to /root/reference/weathernext).  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the parameter name starts with `h_`; the caller owns all memory;
+ *   - all work is enqueued on the caller's stream (`void* stream` is a
+ *     hipStream_t; pass torch.cuda.current_stream().cuda_stream); nothing here
+ *     allocates, frees or synchronises (except gc_time_program, a measurement
+ *     helper that synchronises by design);
+ *   - return 0 on success, a negative GC_E* code otherwise; the message is in
+ *     gc_last_error() (thread-local);
+ *   - fp32 everywhere; latent size is fixed at 512 (GraphCast's
+ *     `latent_size`, weathernext1_graph/graphcast.py:123) and MLPs have exactly
+ *     one hidden layer (`hidden_layers`, :124) -- other values are rejected
+ *     loudly by the host code.
+ *
+ * Packed weight layout ("k4-interleaved"): a haiku `w` of shape [K, N]
+ * (x @ w, utils/legacy/deep_typed_graph_net.py:206-208) is stored as
+ * Wp[K/4][NP][4] with Wp[q][n][j] = w[4q + j][n]; K is zero-padded to a
+ * multiple of 32 and N to NP = 512 (or 256 for the decoder's last layer).
+ * A 32-row K chunk is then one contiguous 8*NP*16-byte block that is DMA'd
+ * linearly into LDS and read conflict-free as ds_read_b128 MFMA A-fragments.
+ */
+#ifndef GCAST_H_
+#define GCAST_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GC_LATENT 512
+#define GC_TILE_ROWS 64          /* rows per workgroup tile (4 waves x 16) */
+#define GC_K_CHUNK 32            /* K rows per LDS weight chunk */
+
+#define GC_EINVAL (-1)
+#define GC_ELAUNCH (-2)
+
+/* What a fused row-MLP launch produces. */
+enum gc_rowmlp_mode {
+  /* out = A.W1 + addends            (no activation, no layer 2)            */
+  GC_MODE_LINEAR = 0,
+  /* out = [res +] LN(swish(A.W1 + addends).W2 + b2), N2 = 512;
+   * optionally also segment-summed over receiver-sorted rows               */
+  GC_MODE_MLP_LN = 1,
+  /* out = swish(A.W1 + addends).W2 + b2, N2 <= 256, no LayerNorm (decoder) */
+  GC_MODE_MLP_OUT = 2
+};
+
+/* One fused "rows -> MLP (-> LayerNorm) (-> residual) (-> segment-sum)" launch.
+ *
+ * Replaces, per reference call site:
+ *   - hk.nets.MLP + hk.LayerNorm built at deep_typed_graph_net.py:205-247
+ *     (embedders :250-271, processor :294-311, decoder :313-322);
+ *   - the sender/receiver row gathers of typed_graph_net.py:431-447 (`g0/idx0`,
+ *     `g1/idx1`, applied AFTER the W1 product: x[idx].W == (x.W)[idx]);
+ *   - jraph.concatenated_args (deep_typed_graph_net.py:209,247): the concat
+ *     [a0 | a1] is realised as two K-slices of W1;
+ *   - the residual of deep_typed_graph_net.py:380-392 (`res`);
+ *   - jraph.segment_sum over receivers, typed_graph_net.py:532-538 (`seg`).
+ *
+ * layer-1 pre-activation  z[r,:] = a0[r,:k0].W1[:k0] + a1[r,:k1].W1[k0:k0+k1]
+ *                                  + d[r,:] + g0[idx0[r],:] + g1[idx1[r],:] + b1
+ */
+typedef struct gc_rowmlp_desc {
+  int mode;                /* enum gc_rowmlp_mode */
+  int n_rows;              /* rows to process */
+  /* layer-1 GEMM sources (row-major, 16-byte aligned rows); k0,k1 multiples of 32, may be 0 */
+  const float* a0; int lda0; int k0;
+  const float* a1; int lda1; int k1;
+  const float* w1p;        /* packed [(k0+k1)/4][512][4]; NULL iff k0+k1 == 0 */
+  /* addends to the pre-activation (each may be NULL) */
+  const float* d;  int ldd;          /* direct rows d[r] */
+  const float* g0; const int* idx0;  /* gathered rows g0[idx0[r]], row stride 512 */
+  const float* g1; const int* idx1;
+  const float* b1;         /* [512] */
+  /* layer 2 (modes MLP_LN / MLP_OUT) */
+  const float* w2p;        /* packed [128][NP][4], NP = 512 (MLP_LN) or 256 (MLP_OUT) */
+  const float* b2;         /* [NP] (zero padded) */
+  int n2;                  /* real output width: 512 (MLP_LN), <= 240 (MLP_OUT) */
+  /* LayerNorm (mode MLP_LN; NULL scale => skip) */
+  const float* ln_scale; const float* ln_offset;
+  /* residual and store */
+  const float* res; int ldres;       /* added after LayerNorm; may alias out */
+  float* out; int ldo;               /* NULL => nothing stored (segment-sum only) */
+  /* segment-sum of the (pre-residual) rows over receiver-sorted, tile-packed rows
+   * (mode MLP_LN only; n_rows must be a multiple of GC_TILE_ROWS) */
+  const int* seg;          /* [n_rows] receiver id per row, -1 = padding row; NULL => off */
+  const int* tile_flags;   /* [n_rows/64] bit0: first run continues the previous tile,
+                                          bit1: last run continues into the next tile */
+  float* agg;              /* [n_receivers][512] rows owned entirely by one tile */
+  float* partial;          /* [2*n_rows/64][512] straddling partial sums */
+} gc_rowmlp_desc;
+
+int gc_rowmlp(const gc_rowmlp_desc* desc, void* stream);
+
+/* Deterministic combine of straddling segment partials (no float atomics):
+ * agg[recv[i]] = partial[2*t0[i]+1] + sum_{t=t0[i]+1..t1[i]} partial[2*t].
+ * Completes jraph.segment_sum (typed_graph_net.py:532-538). */
+int gc_seg_fixup(int n_entries, const int* recv, const int* t0, const int* t1,
+                 const float* partial, float* agg, void* stream);
+
+/* agg[rows[i], :] = 0 for receivers without incoming edges (segment_sum's
+ * "zeros for empty segments"). */
+int gc_zero_rows(int n, const int* rows, float* agg, void* stream);
+
+/* xin[r, :] = [ x[r, b, 0:c_in] | node_struct[r, 0:n_struct] | 0-pad ] (row stride kp).
+ * Replaces the concat + batch broadcast of graphcast.py:561-568 for batch
+ * element b of x [n_rows, batch, c_in]. */
+int gc_prep_grid_input(int n_rows, int batch, int b, int c_in, const float* x,
+                       int n_struct, const float* node_struct, int kp, float* xin,
+                       void* stream);
+
+/* A recorded sequence of launches = one encode-process-decode step
+ * (graphcast.py:306-323 between _inputs_to_grid_node_features and
+ * _grid_node_outputs_to_prediction). */
+enum gc_op_kind { GC_OP_ROWMLP = 0, GC_OP_FIXUP = 1, GC_OP_ZERO = 2, GC_OP_PREP = 3 };
+
+typedef struct gc_op {
+  int kind;                /* enum gc_op_kind */
+  int tag;                 /* caller-defined stage id, reported back by gc_time_program */
+  gc_rowmlp_desc mlp;      /* GC_OP_ROWMLP */
+  /* GC_OP_FIXUP / GC_OP_ZERO */
+  int n; const int* i0; const int* i1; const int* i2;
+  const float* src; float* dst;
+  /* GC_OP_PREP */
+  int batch, b, c_in, n_struct, kp;
+  const float* x; const float* node_struct;
+} gc_op;
+
+int gc_run_program(const gc_op* h_ops, int n_ops, void* stream);
+
+/* Measurement helper: runs the program `iters` times, bracketing EVERY op with
+ * hipEvents on `stream`; h_ms[i] receives the mean milliseconds of op i.
+ * Synchronises the stream.  Not used on the product path. */
+int gc_time_program(const gc_op* h_ops, int n_ops, int iters, float* h_ms, void* stream);
+
+/* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for what == 1, 0 otherwise:
+ * lets a foreign-language binding verify its struct layout at load time. */
+size_t gc_abi_sizeof(int what);
+
+const char* gc_last_error(void);
+/* Build fingerprint: "gfx950;stage=<glds|regs>;..." */
+const char* gc_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* GCAST_H_ */

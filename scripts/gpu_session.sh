@@ -1,0 +1,42 @@
+#!/bin/bash
+# One GPU-box session: smoke, GPU parity tests (both LDS-staging variants if needed),
+# bench line, rocprofv3 kernel trace.  Everything is logged under gpurun_out/.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/${1:-session}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+rocm-smi --showproductname 2>/dev/null | head -8 > "$OUT/gpu.txt"
+
+echo "== smoke" | tee "$OUT/summary.txt"
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
+echo "smoke rc=$?" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
+
+echo "== pytest -m gpu (glds)" | tee -a "$OUT/summary.txt"
+timeout 1200 python -m pytest tests -m gpu -q -rA --timeout=600 > "$OUT/pytest_gpu.log" 2>&1
+RC=$?
+echo "pytest rc=$RC" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
+if [ $RC -ne 0 ]; then
+  echo "== pytest -m gpu (regs variant)" | tee -a "$OUT/summary.txt"
+  GCAST_LIB_VARIANT=regs timeout 1200 python -m pytest tests -m gpu -q -rA --timeout=600 > "$OUT/pytest_gpu_regs.log" 2>&1
+  echo "pytest(regs) rc=$?" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest_gpu_regs.log" | tee -a "$OUT/summary.txt"
+  if [ "${FALLBACK_TO_REGS:-1}" = "1" ] && tail -1 "$OUT/pytest_gpu_regs.log" | grep -q passed && ! tail -1 "$OUT/pytest_gpu_regs.log" | grep -q failed; then
+    export GCAST_LIB_VARIANT=regs
+    echo "continuing with GCAST_LIB_VARIANT=regs" | tee -a "$OUT/summary.txt"
+  fi
+fi
+
+echo "== bench" | tee -a "$OUT/summary.txt"
+timeout 1500 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "$OUT/summary.txt"; tail -5 "$OUT/bench.err" | tee -a "$OUT/summary.txt"
+
+if [ "${DO_PROF:-1}" = "1" ]; then
+  echo "== rocprofv3 kernel trace" | tee -a "$OUT/summary.txt"
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o trace -- \
+      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --op-timing-iters 1 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
+  echo "rocprof rc=$?" | tee -a "$OUT/summary.txt"
+  find "$OUT/prof" -name "*stats*" | head | tee -a "$OUT/summary.txt"
+  for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do head -20 "$f" | tee -a "$OUT/summary.txt"; done
+  # keep only the small summaries (the raw trace can be large)
+  find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
+fi

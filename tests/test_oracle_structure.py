@@ -1,0 +1,136 @@
+"""Pins the oracle's STRUCTURE half against fixtures produced by the reference's
+own code (tests/golden/make_golden.py) and against the reference's known-answer
+tests (icosahedral_mesh_test.py, grid_mesh_connectivity_test.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import connectivity, features, graphcast as ogc, mesh
+
+
+def sha(a):
+  return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+  return dict(np.load(os.path.join(golden_dir, "structure_tiny.npz")))
+
+
+@pytest.fixture(scope="module")
+def hashes(golden_dir):
+  with open(os.path.join(golden_dir, "structure_hashes.json")) as f:
+    return json.load(f)
+
+
+def test_icosahedron_counts():
+  # icosahedral_mesh_test.py:36-39
+  v, f = mesh.icosahedron()
+  assert v.shape == (12, 3) and f.shape == (20, 3)
+  assert v.dtype == np.float32 and f.dtype == np.int32
+
+
+def test_hierarchy_properties():
+  # icosahedral_mesh_test.py:41-59,94-126
+  levels = mesh.mesh_hierarchy(4)
+  nv, nf = 12, 20
+  for i, (v, f) in enumerate(levels):
+    assert v.shape == (nv, 3) and f.shape == (nf, 3)
+    np.testing.assert_allclose(np.linalg.norm(v, axis=1), 1.0, rtol=1e-6)
+    tri = v[f].astype(np.float64)
+    normal = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 1])
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    centre = tri.mean(1)
+    centre /= np.linalg.norm(centre, axis=1, keepdims=True)
+    np.testing.assert_allclose((normal * centre).sum(1), 1.0, atol=6e-4)
+    if i:
+      np.testing.assert_array_equal(v[:len(levels[i - 1][0])], levels[i - 1][0])
+    nv, nf = nv + 3 * nf // 2, 4 * nf
+
+
+def test_faces_to_edges_known_answer():
+  # icosahedral_mesh_test.py:72-91
+  s, r = mesh.faces_to_edges(np.array([[0, 1, 2], [3, 4, 5]]))
+  np.testing.assert_array_equal(np.stack([s, r], -1),
+                                [[0, 1], [3, 4], [1, 2], [4, 5], [2, 0], [5, 3]])
+
+
+def test_merge_meshes():
+  # icosahedral_mesh_test.py:61-70
+  levels = mesh.mesh_hierarchy(2)
+  merged = mesh.merged_faces(levels)
+  assert merged.shape[0] == sum(f.shape[0] for _, f in levels)
+  np.testing.assert_array_equal(merged[:20], levels[0][1])
+
+
+def test_grid_xyz_known_answer():
+  # grid_mesh_connectivity_test.py:23-47
+  lat = np.array([-45.0, 0.0, 45.0])
+  lon = np.array([0.0, 90.0, 180.0, 270.0])
+  inv = 1 / np.sqrt(2)
+  want = np.array([
+      [[inv, 0, -inv], [0, inv, -inv], [-inv, 0, -inv], [0, -inv, -inv]],
+      [[1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, -1, 0]],
+      [[inv, 0, inv], [0, inv, inv], [-inv, 0, inv], [0, -inv, inv]]])
+  np.testing.assert_allclose(connectivity.grid_xyz(lat, lon), want, atol=1e-15)
+
+
+def test_tiny_structure_matches_reference(tiny):
+  g = ogc.build_graphs(tiny["lat"], tiny["lon"], mesh_size=2)
+  np.testing.assert_array_equal(g["mesh_vertices"], tiny["mesh_vertices"])
+  np.testing.assert_array_equal(g["mesh_faces"], tiny["mesh_faces"])
+  assert repr(float(g["radius"])) == repr(float(tiny["radius"]))
+  np.testing.assert_array_equal(g["g2m"]["senders"], tiny["g2m_grid_idx"])
+  np.testing.assert_array_equal(g["g2m"]["receivers"], tiny["g2m_mesh_idx"])
+  np.testing.assert_array_equal(g["mesh"]["senders"], tiny["mesh_senders"])
+  np.testing.assert_array_equal(g["mesh"]["receivers"], tiny["mesh_receivers"])
+  np.testing.assert_allclose(g["grid_node_feat"], tiny["grid_node_feat"], rtol=0, atol=1e-7)
+  np.testing.assert_allclose(g["mesh_node_feat"], tiny["mesh_node_feat"], rtol=0, atol=1e-7)
+  np.testing.assert_allclose(g["mesh_node_feat"], tiny["mesh_node_feat_bipartite"], atol=1e-7)
+  np.testing.assert_allclose(g["g2m"]["feat"], tiny["g2m_edge_feat"], rtol=0, atol=1e-12)
+  np.testing.assert_allclose(g["mesh"]["feat"], tiny["mesh_edge_feat"], rtol=0, atol=1e-12)
+  np.testing.assert_allclose(connectivity.grid_xyz(tiny["lat"], tiny["lon"]),
+                             tiny["grid_xyz"], atol=1e-7)
+
+
+def _check_against_hashes(entry, res, mesh_size):
+  lat = np.arange(-90, 90 + res / 2, res).astype(np.float32)
+  lon = np.arange(0, 360, res).astype(np.float32)
+  levels = mesh.mesh_hierarchy(mesh_size)
+  v, f = levels[-1]
+  assert sha(f) == entry["mesh_faces"]["sha256_16"]
+  assert sha(v) == entry["mesh_vertices"]["sha256_16_as_f32"]
+  radius = mesh.max_edge_length(v, f) * 0.6
+  assert repr(float(radius)) == entry["radius_repr"]
+  ms, mr = mesh.faces_to_edges(mesh.merged_faces(levels))
+  assert sha(ms) == entry["mesh_senders"]["sha256_16"]
+  assert sha(mr) == entry["mesh_receivers"]["sha256_16"]
+  gi, mi = connectivity.radius_query(lat, lon, v, radius)
+  assert gi.dtype == np.dtype(entry["g2m_grid_idx"]["dtype"])
+  assert sha(gi) == entry["g2m_grid_idx"]["sha256_16"]
+  assert sha(mi) == entry["g2m_mesh_idx"]["sha256_16"]
+  mlat, mlon = features.cartesian_to_lat_lon(v)
+  glon, glat = np.meshgrid(lon, lat)
+  glat = glat.reshape(-1).astype(np.float32)
+  glon = glon.reshape(-1).astype(np.float32)
+  ef, _ = features.edge_features(glat, glon, mlat, mlon, gi, mi)
+  np.testing.assert_allclose(np.abs(ef).sum(dtype=np.float64),
+                             entry["g2m_edge_feat"]["abs_sum_f64"], rtol=1e-9)
+  ef, _ = features.edge_features(mlat, mlon, mlat, mlon, ms, mr)
+  np.testing.assert_allclose(np.abs(ef).sum(dtype=np.float64),
+                             entry["mesh_edge_feat"]["abs_sum_f64"], rtol=1e-9)
+  nf = features.node_features(glat, glon)
+  np.testing.assert_allclose(np.abs(nf).sum(dtype=np.float64),
+                             entry["grid_node_feat"]["abs_sum_f64"], rtol=1e-6)
+
+
+def test_1deg_structure_fingerprints(hashes):
+  _check_against_hashes(hashes["1deg_M5"], 1.0, 5)
+
+
+@pytest.mark.slow
+def test_0p25deg_structure_fingerprints(hashes):
+  _check_against_hashes(hashes["0p25deg_M6"], 0.25, 6)

@@ -1,0 +1,110 @@
+"""Host-side layout logic (CPU): packed weights, receiver-sorted tile packing and the
+segment-sum metadata.  The device algorithm (tile kernel + fixup + zero rows) is
+emulated step by step in numpy and compared with a plain scatter-add."""
+import numpy as np
+import pytest
+
+from graphcast_amd import packing
+
+
+def test_pack_weight_roundtrip_and_layout():
+  rng = np.random.default_rng(0)
+  w = rng.standard_normal((474, 512)).astype(np.float32)
+  wp = packing.pack_weight(w)
+  assert wp.shape == (480 // 4, 512, 4) and wp.flags["C_CONTIGUOUS"]
+  np.testing.assert_array_equal(packing.unpack_weight(wp, 474, 512), w)
+  assert wp[5, 17, 2] == w[4 * 5 + 2, 17]
+  assert (wp[474 // 4 + 1:] == 0).all()           # zero padded K rows
+  w2 = rng.standard_normal((512, 227)).astype(np.float32)
+  wp2 = packing.pack_weight(w2, np_cols=256)
+  assert wp2.shape == (128, 256, 4)
+  np.testing.assert_array_equal(packing.unpack_weight(wp2, 512, 227), w2)
+  assert (wp2[:, 227:, :] == 0).all()
+  with pytest.raises(ValueError):
+    packing.pack_weight(w, np_cols=256)
+
+
+def emulate_device_segment_sum(rows, pk, n_receivers):
+  """Mirror of rowmlp_kernel's segment epilogue + seg_fixup_kernel + zero_rows_kernel."""
+  n_tiles = pk.n_rows // packing.TILE
+  agg = np.full((n_receivers, rows.shape[1]), np.nan, dtype=rows.dtype)   # poison
+  partial = np.full((2 * n_tiles, rows.shape[1]), np.nan, dtype=rows.dtype)
+  for t in range(n_tiles):
+    segs = pk.receivers[t * 64:(t + 1) * 64]
+    flags = pk.tile_flags[t]
+    cur, run_start, acc = -1, 0, 0.0
+    for r in range(65):
+      sid = segs[r] if r < 64 else -2
+      if sid != cur:
+        if cur >= 0:
+          if run_start == 0 and (flags & 1):
+            partial[2 * t] = acc
+          elif r == 64 and (flags & 2):
+            partial[2 * t + 1] = acc
+          else:
+            assert np.isnan(agg[cur]).all(), "receiver written twice"
+            agg[cur] = acc
+        cur, run_start, acc = sid, r, 0.0
+      if sid >= 0:
+        acc = acc + rows[t * 64 + r]
+  for rcv, t0, t1 in zip(pk.fix_recv, pk.fix_t0, pk.fix_t1):
+    s = partial[2 * t0 + 1].copy()
+    for t in range(t0 + 1, t1 + 1):
+      s += partial[2 * t]
+    assert np.isnan(agg[rcv]).all()
+    agg[rcv] = s
+  for rcv in pk.empty_receivers:
+    agg[rcv] = 0
+  return agg
+
+
+@pytest.mark.parametrize("case", ["mesh_like", "skewed", "uniform3", "uniform4", "with_empty",
+                                  "single_giant"])
+def test_pack_edges_segment_sum(case):
+  rng = np.random.default_rng(1)
+  if case == "mesh_like":
+    n_recv, deg = 500, rng.integers(5, 37, 500)
+  elif case == "skewed":
+    n_recv, deg = 60, rng.integers(1, 40, 60)
+    deg[7], deg[8] = 700, 131                      # pole-like receivers spanning many tiles
+  elif case == "uniform3":
+    n_recv, deg = 1000, np.full(1000, 3)
+  elif case == "uniform4":
+    n_recv, deg = 100, np.full(100, 4)             # 64 % 4 == 0 -> plain packing
+  elif case == "with_empty":
+    n_recv, deg = 300, rng.integers(0, 9, 300)
+    deg[0] = deg[299] = 0
+  else:
+    n_recv, deg = 3, np.array([1, 1000, 2])
+  receivers = rng.permutation(np.repeat(np.arange(n_recv), deg))
+  senders = rng.integers(0, 77, len(receivers))
+  pk = packing.pack_edges(senders, receivers, n_recv)
+  assert pk.n_rows % 64 == 0 and pk.n_edges == len(receivers)
+  ok = pk.perm >= 0
+  # packed rows are a permutation of the original edges with consistent indices
+  np.testing.assert_array_equal(np.sort(pk.perm[ok]), np.arange(len(receivers)))
+  np.testing.assert_array_equal(pk.senders[ok], senders[pk.perm[ok]])
+  np.testing.assert_array_equal(pk.receivers[ok], receivers[pk.perm[ok]])
+  assert (pk.senders[~ok] == -1).all() and (pk.receivers[~ok] == -1).all()
+  valid_rcv = pk.receivers[ok]
+  assert (np.diff(valid_rcv) >= 0).all()           # receiver-sorted
+  # stable: original order is kept inside a segment
+  same = valid_rcv[1:] == valid_rcv[:-1]
+  assert (np.diff(pk.perm[ok])[same] > 0).all()
+  if case == "uniform3":
+    assert len(pk.fix_recv) == 0 and (pk.tile_flags == 0).all()
+    assert pk.n_rows == -(-len(receivers) // 63) * 64
+  rows = rng.standard_normal((pk.n_rows, 8))
+  rows[~ok] = 1e30                                  # padding rows must never be read
+  want = packing.segment_sum_packed_reference(rows, pk, n_recv)
+  got = emulate_device_segment_sum(rows, pk, n_recv)
+  assert not np.isnan(got).any()
+  np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+  np.testing.assert_array_equal(pk.empty_receivers, np.flatnonzero(deg == 0))
+
+
+def test_pack_edges_rejects_bad_input():
+  with pytest.raises(ValueError):
+    packing.pack_edges(np.array([], dtype=int), np.array([], dtype=int), 3)
+  with pytest.raises(ValueError):
+    packing.pack_edges(np.array([0]), np.array([3]), 3)

@@ -1,0 +1,267 @@
+"""GPU parity of the fused row-MLP kernel family (through the C-ABI) against the
+oracle's numpy primitives in float64.  Tolerance: fp32 MFMA is an exact-fp32 fma
+chain, so per-element error is fp32 round-off class; we require rel-RMSE <= 2e-6
+(two orders inside the 1e-4 budget of BASELINE.json) and max-abs <= 2e-4."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from graphcast_amd import _native as nat          # noqa: E402
+from graphcast_amd import packing                 # noqa: E402
+from oracle import gnn as ognn                    # noqa: E402
+
+D = 512
+REL_RMSE_TOL = 2e-6
+MAX_ABS_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  return torch.device("cuda:0")
+
+
+def up(a, dev, dtype=np.float32):
+  return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).to(dev)
+
+
+def run(desc):
+  lib = nat.lib()
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  nat.check(lib.gc_rowmlp(ctypes.byref(desc), stream), "gc_rowmlp")
+  torch.cuda.synchronize()
+
+
+def assert_close(got, want, what):
+  got = np.asarray(got, dtype=np.float64)
+  err = np.linalg.norm(got - want) / np.linalg.norm(want)
+  assert np.isfinite(got).all(), what
+  assert err <= REL_RMSE_TOL, f"{what}: rel-RMSE {err:.3e}"
+  assert np.abs(got - want).max() <= MAX_ABS_TOL * max(1.0, np.abs(want).max()), what
+
+
+def asymmetric_weight(rng, k, n):
+  # random + a deterministic asymmetric ramp: a transposed or permuted K/N index shows up
+  return (rng.standard_normal((k, n)) / np.sqrt(k) + 1e-3 * np.arange(k)[:, None] / k
+          - 2e-3 * np.arange(n)[None, :] / n).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_rows", [64, 100, 1000])
+@pytest.mark.parametrize("k", [32, 480, 512])
+def test_linear_mode(dev, n_rows, k):
+  rng = np.random.default_rng(k + n_rows)
+  a = rng.standard_normal((n_rows, k)).astype(np.float32)
+  w = asymmetric_weight(rng, k, D)
+  b1 = rng.standard_normal(D).astype(np.float32)
+  ta, tw, tb = up(a, dev), up(packing.pack_weight(w), dev), up(b1, dev)
+  out = torch.zeros((n_rows, D), device=dev)
+  d = nat.RowMlpDesc()
+  d.mode, d.n_rows = nat.MODE_LINEAR, n_rows
+  d.a0, d.lda0, d.k0, d.w1p, d.b1 = ta.data_ptr(), k, k, tw.data_ptr(), tb.data_ptr()
+  d.out, d.ldo = out.data_ptr(), D
+  run(d)
+  assert_close(out.cpu().numpy(), a.astype(np.float64) @ w + b1, f"linear k={k}")
+
+
+def test_linear_identity_weight_detects_transposes(dev):
+  rng = np.random.default_rng(5)
+  a = rng.standard_normal((64, D)).astype(np.float32)
+  ta, tw = up(a, dev), up(packing.pack_weight(np.eye(D, dtype=np.float32)), dev)
+  out = torch.zeros((64, D), device=dev)
+  d = nat.RowMlpDesc()
+  d.mode, d.n_rows = nat.MODE_LINEAR, 64
+  d.a0, d.lda0, d.k0, d.w1p = ta.data_ptr(), D, D, tw.data_ptr()
+  d.out, d.ldo = out.data_ptr(), D
+  run(d)
+  np.testing.assert_array_equal(out.cpu().numpy(), a)     # exact: one product per output
+
+
+def test_linear_with_gathers_and_direct_addend(dev):
+  rng = np.random.default_rng(7)
+  n_rows, n_src = 300, 50
+  a = rng.standard_normal((n_rows, D)).astype(np.float32)
+  w = asymmetric_weight(rng, D, D)
+  dd = rng.standard_normal((n_rows, D)).astype(np.float32)
+  g0 = rng.standard_normal((n_src, D)).astype(np.float32)
+  g1 = rng.standard_normal((n_src, D)).astype(np.float32)
+  i0 = rng.integers(0, n_src, n_rows).astype(np.int32)
+  i1 = rng.integers(0, n_src, n_rows).astype(np.int32)
+  t = [up(x, dev) for x in (a, packing.pack_weight(w), dd, g0, g1)]
+  ti0, ti1 = up(i0, dev, np.int32), up(i1, dev, np.int32)
+  out = torch.zeros((n_rows, D), device=dev)
+  d = nat.RowMlpDesc()
+  d.mode, d.n_rows = nat.MODE_LINEAR, n_rows
+  d.a0, d.lda0, d.k0, d.w1p = t[0].data_ptr(), D, D, t[1].data_ptr()
+  d.d, d.ldd = t[2].data_ptr(), D
+  d.g0, d.idx0, d.g1, d.idx1 = t[3].data_ptr(), ti0.data_ptr(), t[4].data_ptr(), ti1.data_ptr()
+  d.out, d.ldo = out.data_ptr(), D
+  run(d)
+  want = a.astype(np.float64) @ w + dd + g0[i0] + g1[i1]
+  assert_close(out.cpu().numpy(), want, "linear+gathers")
+
+
+def _mlp_ln_case(rng, n_rows, k0, k1):
+  p = dict(
+      a0=rng.standard_normal((n_rows, k0)).astype(np.float32) if k0 else None,
+      a1=rng.standard_normal((n_rows, k1)).astype(np.float32) if k1 else None,
+      w1=asymmetric_weight(rng, max(k0 + k1, 1), D) if k0 else None,
+      b1=(0.3 * rng.standard_normal(D)).astype(np.float32),
+      w2=asymmetric_weight(rng, D, D),
+      b2=(0.3 * rng.standard_normal(D)).astype(np.float32),
+      scale=(1 + 0.2 * rng.standard_normal(D)).astype(np.float32),
+      offset=(0.2 * rng.standard_normal(D)).astype(np.float32))
+  return p
+
+
+def _mlp_ln_want(p, extra=0.0):
+  z = extra + p["b1"].astype(np.float64)
+  if p["a0"] is not None:
+    a = p["a0"] if p["a1"] is None else np.concatenate([p["a0"], p["a1"]], axis=1)
+    z = z + a.astype(np.float64) @ p["w1"]
+  y = ognn.swish(z) @ p["w2"].astype(np.float64) + p["b2"]
+  return ognn.layer_norm(y, p["scale"].astype(np.float64), p["offset"].astype(np.float64))
+
+
+@pytest.mark.parametrize("n_rows,k0,k1", [(64, 512, 0), (130, 480, 0), (257, 512, 512), (64, 32, 0)])
+def test_mlp_ln_mode_with_residual(dev, n_rows, k0, k1):
+  rng = np.random.default_rng(n_rows + k0 + k1)
+  p = _mlp_ln_case(rng, n_rows, k0, k1)
+  res = rng.standard_normal((n_rows, D)).astype(np.float32)
+  keep = [up(p["a0"], dev), up(packing.pack_weight(p["w1"]), dev), up(p["b1"], dev),
+          up(packing.pack_weight(p["w2"]), dev), up(p["b2"], dev), up(p["scale"], dev),
+          up(p["offset"], dev), up(res, dev)]
+  ta1 = up(p["a1"], dev) if k1 else None
+  out = torch.zeros((n_rows, D), device=dev)
+  d = nat.RowMlpDesc()
+  d.mode, d.n_rows = nat.MODE_MLP_LN, n_rows
+  d.a0, d.lda0, d.k0, d.w1p, d.b1 = keep[0].data_ptr(), k0, k0, keep[1].data_ptr(), keep[2].data_ptr()
+  if k1:
+    d.a1, d.lda1, d.k1 = ta1.data_ptr(), k1, k1
+  d.w2p, d.b2, d.n2 = keep[3].data_ptr(), keep[4].data_ptr(), D
+  d.ln_scale, d.ln_offset = keep[5].data_ptr(), keep[6].data_ptr()
+  d.res, d.ldres, d.out, d.ldo = keep[7].data_ptr(), D, out.data_ptr(), D
+  run(d)
+  assert_close(out.cpu().numpy(), _mlp_ln_want(p) + res, f"mlp_ln k0={k0} k1={k1}")
+  # in place (out aliases res) must give the same bits
+  inplace = keep[7].clone()
+  d.res, d.out = inplace.data_ptr(), inplace.data_ptr()
+  run(d)
+  assert torch.equal(inplace, out)
+
+
+@pytest.mark.parametrize("case", ["mesh_like", "skewed", "uniform3", "with_empty"])
+def test_edge_block_with_segment_sum(dev, case):
+  """The fused edge kernel: gathers -> MLP -> LN -> segment-sum (+fixup, +zero rows)."""
+  rng = np.random.default_rng(11)
+  if case == "mesh_like":
+    n_recv, deg = 400, rng.integers(5, 37, 400)
+  elif case == "skewed":
+    n_recv, deg = 40, rng.integers(1, 30, 40)
+    deg[3], deg[4] = 700, 131
+  elif case == "uniform3":
+    n_recv, deg = 500, np.full(500, 3)
+  else:
+    n_recv, deg = 200, rng.integers(0, 9, 200)
+    deg[0] = deg[199] = 0
+  receivers = rng.permutation(np.repeat(np.arange(n_recv), deg))
+  n_send = 90
+  senders = rng.integers(0, n_send, len(receivers))
+  pk = packing.pack_edges(senders, receivers, n_recv)
+  p = _mlp_ln_case(rng, pk.n_rows, 0, 0)
+  dd = rng.standard_normal((pk.n_rows, D)).astype(np.float32)
+  gs = rng.standard_normal((n_send, D)).astype(np.float32)
+  gr = rng.standard_normal((n_recv, D)).astype(np.float32)
+  t = dict(d=up(dd, dev), gs=up(gs, dev), gr=up(gr, dev), b1=up(p["b1"], dev),
+           w2=up(packing.pack_weight(p["w2"]), dev), b2=up(p["b2"], dev),
+           sc=up(p["scale"], dev), of=up(p["offset"], dev),
+           snd=up(pk.senders, dev, np.int32), rcv=up(pk.receivers, dev, np.int32),
+           flags=up(pk.tile_flags, dev, np.int32))
+  agg = torch.full((n_recv, D), float("nan"), device=dev)
+  partial = torch.full((2 * pk.n_rows // 64, D), float("nan"), device=dev)
+  out = torch.zeros((pk.n_rows, D), device=dev)
+  d = nat.RowMlpDesc()
+  d.mode, d.n_rows = nat.MODE_MLP_LN, pk.n_rows
+  d.d, d.ldd = t["d"].data_ptr(), D
+  d.g0, d.idx0, d.g1, d.idx1 = t["gs"].data_ptr(), t["snd"].data_ptr(), t["gr"].data_ptr(), t["rcv"].data_ptr()
+  d.b1, d.w2p, d.b2, d.n2 = t["b1"].data_ptr(), t["w2"].data_ptr(), t["b2"].data_ptr(), D
+  d.ln_scale, d.ln_offset = t["sc"].data_ptr(), t["of"].data_ptr()
+  d.out, d.ldo = out.data_ptr(), D
+  d.seg, d.tile_flags = t["rcv"].data_ptr(), t["flags"].data_ptr()
+  d.agg, d.partial = agg.data_ptr(), partial.data_ptr()
+  lib = nat.lib()
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+  def pipeline():
+    nat.check(lib.gc_rowmlp(ctypes.byref(d), stream), "gc_rowmlp")
+    if len(pk.fix_recv):
+      f = [up(x, dev, np.int32) for x in (pk.fix_recv, pk.fix_t0, pk.fix_t1)]
+      nat.check(lib.gc_seg_fixup(len(pk.fix_recv), f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(),
+                                 partial.data_ptr(), agg.data_ptr(), stream), "gc_seg_fixup")
+    if len(pk.empty_receivers):
+      z = up(pk.empty_receivers, dev, np.int32)
+      nat.check(lib.gc_zero_rows(len(z), z.data_ptr(), agg.data_ptr(), stream), "gc_zero_rows")
+    torch.cuda.synchronize()
+
+  pipeline()
+  ok = pk.receivers >= 0
+  extra = dd.astype(np.float64) + gs[np.maximum(pk.senders, 0)] + gr[np.maximum(pk.receivers, 0)]
+  e_new = _mlp_ln_want(p, extra)
+  assert_close(out.cpu().numpy()[ok], e_new[ok], f"edge rows {case}")
+  want = ognn.segment_sum(e_new[ok], pk.receivers[ok], n_recv)
+  got = agg.cpu().numpy()
+  assert np.isfinite(got).all(), "segment-sum left poisoned rows"
+  scale = max(1.0, np.abs(want).max())
+  assert np.abs(got - want).max() <= MAX_ABS_TOL * scale
+  assert np.linalg.norm(got - want) <= 4e-6 * np.linalg.norm(want)
+  # deterministic: a second run gives identical bits (no float atomics anywhere)
+  first = agg.clone()
+  agg.fill_(float("nan"))
+  pipeline()
+  assert torch.equal(first, agg)
+
+
+@pytest.mark.parametrize("n_rows,n2,batch", [(64, 227, 1), (500, 83, 2), (70, 240, 1)])
+def test_mlp_out_mode(dev, n_rows, n2, batch):
+  rng = np.random.default_rng(n2)
+  a = rng.standard_normal((n_rows, D)).astype(np.float32)
+  w1, b1 = asymmetric_weight(rng, D, D), (0.3 * rng.standard_normal(D)).astype(np.float32)
+  w2, b2 = asymmetric_weight(rng, D, n2), (0.3 * rng.standard_normal(n2)).astype(np.float32)
+  t = [up(a, dev), up(packing.pack_weight(w1), dev), up(b1, dev),
+       up(packing.pack_weight(w2, np_cols=256), dev), up(packing.pad_vector(b2, 256), dev)]
+  out = torch.full((n_rows, batch, n2), 7.0, device=dev)
+  d = nat.RowMlpDesc()
+  d.mode, d.n_rows = nat.MODE_MLP_OUT, n_rows
+  d.a0, d.lda0, d.k0, d.w1p, d.b1 = t[0].data_ptr(), D, D, t[1].data_ptr(), t[2].data_ptr()
+  d.w2p, d.b2, d.n2 = t[3].data_ptr(), t[4].data_ptr(), n2
+  b = batch - 1
+  d.out, d.ldo = out.data_ptr() + 4 * b * n2, batch * n2
+  run(d)
+  want = ognn.swish(a.astype(np.float64) @ w1 + b1) @ w2.astype(np.float64) + b2
+  got = out.cpu().numpy()
+  assert_close(got[:, b, :], want, f"mlp_out n2={n2}")
+  if batch > 1:
+    assert (got[:, 0, :] == 7.0).all()          # other batch element untouched
+
+
+def test_prep_grid_input(dev):
+  rng = np.random.default_rng(3)
+  n, batch, c_in, kp = 1000, 3, 471, 480
+  x = rng.standard_normal((n, batch, c_in)).astype(np.float32)
+  st = rng.standard_normal((n, 3)).astype(np.float32)
+  tx, ts = up(x, dev), up(st, dev)
+  xin = torch.full((n, kp), float("nan"), device=dev)
+  lib = nat.lib()
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  nat.check(lib.gc_prep_grid_input(n, batch, 1, c_in, tx.data_ptr(), 3, ts.data_ptr(), kp,
+                                   xin.data_ptr(), stream), "gc_prep_grid_input")
+  torch.cuda.synchronize()
+  got = xin.cpu().numpy()
+  np.testing.assert_array_equal(got[:, :c_in], x[:, 1])
+  np.testing.assert_array_equal(got[:, c_in:c_in + 3], st)
+  assert (got[:, c_in + 3:] == 0).all()

@@ -1,0 +1,83 @@
+"""GPU parity of the whole encode-process-decode step (StepEngine through the C-ABI)
+against the float64 oracle, on graphs small enough for the oracle to finish in
+seconds.  Tolerance (BASELINE.json): rel-RMSE <= 1e-4 vs the reference in fp32;
+we assert <= 2e-5 against the float64 oracle and report the measured value."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from graphcast_amd import graphcast as gc          # noqa: E402
+from oracle import graphcast as ogc                # noqa: E402
+from oracle import params as oparams               # noqa: E402
+
+REL_RMSE_TOL = 2e-5
+
+
+def rel_rmse(got, want):
+  return float(np.linalg.norm(np.asarray(got, np.float64) - want) / np.linalg.norm(want))
+
+
+@pytest.fixture(scope="module")
+def small():
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  res, mesh_size, steps = 4.0, 3, 3
+  lat = np.arange(-90, 90 + res / 2, res)
+  lon = np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=steps,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
+  params = oparams.init_params(c_in, c_out, 512, steps, seed=1, nontrivial=True)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(lat, lon)
+  graphs = ogc.build_graphs(lat, lon, mesh_size)
+  return dict(model=model, graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
+
+
+def test_product_graphs_equal_oracle_graphs(small):
+  got, want = small["model"].graph_arrays(), small["graphs"]
+  for k in ("g2m", "mesh", "m2g"):
+    np.testing.assert_array_equal(got[k]["senders"], want[k]["senders"])
+    np.testing.assert_array_equal(got[k]["receivers"], want[k]["receivers"])
+    np.testing.assert_allclose(got[k]["feat"], want[k]["feat"], atol=1e-12)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_step_matches_oracle(small, batch):
+  rng = np.random.default_rng(batch)
+  x = rng.standard_normal((small["graphs"]["n_grid"], batch, small["c_in"])).astype(np.float32)
+  want = ogc.forward(small["params"], small["graphs"], x, steps=small["steps"], dtype=np.float64)
+  y = small["model"].forward_grid_node_features(torch.from_numpy(x).to("cuda:0"))
+  torch.cuda.synchronize()
+  got = y.cpu().numpy()
+  assert got.shape == want.shape == (small["graphs"]["n_grid"], batch, small["c_out"])
+  err = rel_rmse(got, want)
+  print(f"step rel-RMSE vs float64 oracle (batch={batch}): {err:.3e}")
+  assert np.isfinite(got).all()
+  assert err <= REL_RMSE_TOL
+  for b in range(batch):                        # per batch element too
+    assert rel_rmse(got[:, b], want[:, b]) <= REL_RMSE_TOL
+
+
+def test_step_is_deterministic_and_batch_independent(small):
+  rng = np.random.default_rng(9)
+  n = small["graphs"]["n_grid"]
+  x = torch.from_numpy(rng.standard_normal((n, 2, small["c_in"])).astype(np.float32)).to("cuda:0")
+  m = small["model"]
+  y1 = m.forward_grid_node_features(x).clone()
+  y2 = m.forward_grid_node_features(x).clone()
+  assert torch.equal(y1, y2)                    # bitwise: no float atomics
+  y_single = m.forward_grid_node_features(x[:, 1:2].contiguous())
+  assert torch.equal(y_single[:, 0], y1[:, 1])  # batch is a pure broadcast axis (graphcast.py:726-730)
+
+
+def test_missing_params_and_bad_shapes_raise(small):
+  cfg = gc.ModelConfig(resolution=4.0, mesh_size=3, latent_size=512, gnn_msg_steps=3,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  empty = gc.GraphCast(cfg, gc.TASK_13)
+  with pytest.raises(ValueError):
+    empty.forward_grid_node_features(torch.zeros((4, 1, 183), device="cuda:0"))
+  with pytest.raises(ValueError):
+    small["model"].forward_grid_node_features(torch.zeros((5, 1, 183), device="cuda:0"))
