@@ -28,6 +28,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef GC_STAGE_GLDS
 #define GC_STAGE_GLDS 1
 #endif
+#ifndef GC_SCHED_PIN
+#define GC_SCHED_PIN 1
+#endif
 
 namespace {
 
@@ -49,61 +52,118 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Copies one K chunk of packed weights (8 * NP * 4 floats, contiguous) into LDS.
+// One 1 KiB piece (per wave) of a K chunk of packed weights -> LDS.  A chunk of NP
+// columns is 8 * NP * 4 floats = NP / 32 pieces per wave (4 waves).
+__device__ __forceinline__ void stage_piece(const float* __restrict__ gsrc, float* lds, int piece,
+                                            int wave, int lane) {
+  const int off = piece * 1024 + wave * 256;     // wave-uniform float offset of this 1 KiB piece
+#if GC_STAGE_GLDS
+  // LDS destination = wave-uniform base + lane * 16 B (linear image).
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)(gsrc + off + lane * 4),
+      (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+#else
+  const f4 v = *reinterpret_cast<const f4*>(gsrc + off + lane * 4);
+  *reinterpret_cast<f4*>(lds + off + lane * 4) = v;
+#endif
+}
+
+// Copies one whole K chunk of packed weights (8 * NP * 4 floats, contiguous) into LDS.
 template <int NP>
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ gsrc, float* lds, int tid) {
-  constexpr int kFloats = 8 * NP * 4;
-  static_assert(kFloats % 1024 == 0, "chunk must be a whole number of 4 KiB block copies");
+  static_assert((8 * NP * 4) % 1024 == 0, "chunk must be a whole number of 4 KiB block copies");
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-  for (int it = 0; it < kFloats / 1024; ++it) {
-    const int off = it * 1024 + wave * 256;     // wave-uniform float offset of this 1 KiB piece
-#if GC_STAGE_GLDS
-    // LDS destination = wave-uniform base + lane * 16 B (linear image).
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(gsrc + off + lane * 4),
-        (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
-#else
-    const f4 v = *reinterpret_cast<const f4*>(gsrc + off + lane * 4);
-    *reinterpret_cast<f4*>(lds + off + lane * 4) = v;
+  for (int it = 0; it < NP / 32; ++it) stage_piece(gsrc, lds, it, wave, lane);
+}
+
+// acc[nb] += W-chunk(32 k) * B for all n-blocks; b0/b1 are the B operands of the two
+// 16-k halves.  The chunk is walked in "groups" of two n-blocks (8 MFMAs = 256 issue
+// cycles on this SIMD):
+//   * the two A fragments (ds_read_b128) of group t+1 are requested BEFORE the MFMAs
+//     of group t are issued, so the LDS latency hides behind 256 cycles of MFMA
+//     instead of stalling every group (1 wave per SIMD: nobody else covers it);
+//   * dependent MFMAs on one accumulator are 2 issue slots apart (40-cycle dependent
+//     latency vs 32-cycle issue);
+//   * the NEXT chunk's LDS-DMA (NP_NEXT / 32 pieces per wave) is issued one piece per
+//     group over the first groups instead of as one burst in front of the MFMAs.
+// Group T of a chunk (template recursion: the scheduling builtins need constants).
+template <int NBLK, int NP, int NP_NEXT, int T>
+__device__ __forceinline__ void mma_group(f4 (&acc)[kNB], const float* base0, const float* base1,
+                                          f4 a0, f4 a1, f4 b0, f4 b1,
+                                          const float* __restrict__ next_src, float* next_dst,
+                                          int wave, int lane) {
+  constexpr int kGroupsPerHalf = (NBLK + 1) / 2;
+  constexpr int kGroups = 2 * kGroupsPerHalf;
+  constexpr int kPieces = NP_NEXT / 32;
+  static_assert(kPieces <= kGroups, "more staging pieces than MFMA groups");
+  constexpr int s = T / kGroupsPerHalf;
+  constexpr int nb = 2 * (T % kGroupsPerHalf);
+  constexpr bool pair = nb + 1 < NBLK;
+  constexpr bool more = T + 1 < kGroups;
+  constexpr int s2 = (T + 1) / kGroupsPerHalf;
+  constexpr int nb2 = 2 * ((T + 1) % kGroupsPerHalf);
+  constexpr bool pair2 = nb2 + 1 < NBLK;
+  // piece p of the next chunk is issued in group p: all pieces are in flight early in the
+  // chunk, so the barrier that ends it does not wait on a freshly issued DMA
+  constexpr bool piece = T < kPieces;
+  const f4 b = s ? b1 : b0;
+  // Issue order inside a group (held by full scheduling fences; left alone the scheduler
+  // sinks the reads of group T+1 next to their first use and every group stalls on LDS):
+  //   1. the LDS-DMA piece.  hipcc treats global_load_lds as a FLAT access that may touch
+  //      LDS, so the next use of any ds_read result gets s_waitcnt lgkmcnt(0) ...
+  //   2. ... which is why the first MFMA pair comes next: the only reads outstanding are
+  //      this group's fragments, requested 6+ MFMAs (192+ cycles) ago -- the wait is free;
+  //   3. then the A fragments of group T+1 are requested,
+  //   4. and the remaining MFMAs of this group cover their latency.
+  if constexpr (piece) stage_piece(next_src, next_dst, T, wave, lane);
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
 #endif
+  acc[nb] = mfma16(a0.x, b.x, acc[nb]);
+  if constexpr (pair) acc[nb + 1] = mfma16(a1.x, b.x, acc[nb + 1]);
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  f4 n0 = a0, n1 = a1;
+  if constexpr (more) {
+    const float* bs = s2 ? base1 : base0;
+    n0 = *reinterpret_cast<const f4*>(bs + (nb2 * 16 << 2));
+    if constexpr (pair2) n1 = *reinterpret_cast<const f4*>(bs + ((nb2 + 1) * 16 << 2));
+  }
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  if constexpr (pair) {
+    acc[nb] = mfma16(a0.y, b.y, acc[nb]);
+    acc[nb + 1] = mfma16(a1.y, b.y, acc[nb + 1]);
+    acc[nb] = mfma16(a0.z, b.z, acc[nb]);
+    acc[nb + 1] = mfma16(a1.z, b.z, acc[nb + 1]);
+    acc[nb] = mfma16(a0.w, b.w, acc[nb]);
+    acc[nb + 1] = mfma16(a1.w, b.w, acc[nb + 1]);
+  } else {
+    acc[nb] = mfma16(a0.y, b.y, acc[nb]);
+    acc[nb] = mfma16(a0.z, b.z, acc[nb]);
+    acc[nb] = mfma16(a0.w, b.w, acc[nb]);
+  }
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  if constexpr (more) {
+    mma_group<NBLK, NP, NP_NEXT, T + 1>(acc, base0, base1, n0, n1, b0, b1, next_src, next_dst, wave, lane);
   }
 }
 
-// acc[nb] += W-chunk(32 k) * B for all n-blocks; b0/b1 are the B operands of the
-// two 16-k halves.  Blocks are processed in pairs so that dependent MFMAs on one
-// accumulator are 2 issue slots apart (40-cycle dependent latency vs 32-cycle issue).
-template <int NBLK, int NP>
-__device__ __forceinline__ void mma_chunk(f4 (&acc)[kNB], const float* wb, f4 b0, f4 b1,
-                                          int i, int g) {
-  static_assert(NBLK % 2 == 1 || NBLK % 2 == 0, "");
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const f4 b = s ? b1 : b0;
-    const float* base = wb + (((s * 4 + g) * NP + i) << 2);
-#pragma unroll
-    for (int nb = 0; nb + 1 < NBLK; nb += 2) {
-      const f4 a0 = *reinterpret_cast<const f4*>(base + (nb * 16 << 2));
-      const f4 a1 = *reinterpret_cast<const f4*>(base + ((nb + 1) * 16 << 2));
-      acc[nb] = mfma16(a0.x, b.x, acc[nb]);
-      acc[nb + 1] = mfma16(a1.x, b.x, acc[nb + 1]);
-      acc[nb] = mfma16(a0.y, b.y, acc[nb]);
-      acc[nb + 1] = mfma16(a1.y, b.y, acc[nb + 1]);
-      acc[nb] = mfma16(a0.z, b.z, acc[nb]);
-      acc[nb + 1] = mfma16(a1.z, b.z, acc[nb + 1]);
-      acc[nb] = mfma16(a0.w, b.w, acc[nb]);
-      acc[nb + 1] = mfma16(a1.w, b.w, acc[nb + 1]);
-    }
-    if (NBLK & 1) {
-      constexpr int nb = NBLK - 1;
-      const f4 a0 = *reinterpret_cast<const f4*>(base + (nb * 16 << 2));
-      acc[nb] = mfma16(a0.x, b.x, acc[nb]);
-      acc[nb] = mfma16(a0.y, b.y, acc[nb]);
-      acc[nb] = mfma16(a0.z, b.z, acc[nb]);
-      acc[nb] = mfma16(a0.w, b.w, acc[nb]);
-    }
-  }
+template <int NBLK, int NP, int NP_NEXT>
+__device__ __forceinline__ void mma_chunk(f4 (&acc)[kNB], const float* wb, f4 b0, f4 b1, int i, int g,
+                                          const float* __restrict__ next_src, float* next_dst,
+                                          int wave, int lane) {
+  const float* base0 = wb + ((g * NP + i) << 2);
+  const float* base1 = wb + (((4 + g) * NP + i) << 2);
+  const f4 a0 = *reinterpret_cast<const f4*>(base0);
+  const f4 a1 = *reinterpret_cast<const f4*>(base0 + (16 << 2));
+  mma_group<NBLK, NP, NP_NEXT, 0>(acc, base0, base1, a0, a1, b0, b1, next_src, next_dst, wave, lane);
 }
 
 __device__ __forceinline__ float swish1(float x) {
@@ -185,21 +245,30 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
     }
     bn0 = bc0;
     bn1 = bc1;
-    for (int c = 0; c < n1; ++c) {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int c = 0; c + 1 < n1; ++c) {
       __syncthreads();   // chunk c landed in LDS; previous chunk's readers are done
-      if (c + 1 < n1) {
-        stage_chunk<512>(d.w1p + (size_t)(c + 1) * kBufFloats, smem + ((q + 1) & 1) * kBufFloats, tid);
+      {
         const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
         bn0 = *reinterpret_cast<const f4*>(p);
         bn1 = *reinterpret_cast<const f4*>(p + 16);
-      } else if (!kLinear) {
-        stage_chunk<NP2>(d.w2p, smem + ((q + 1) & 1) * kBufFloats, tid);
       }
-      mma_chunk<kNB, 512>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g);
+      mma_chunk<kNB, 512, 512>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g,
+                               d.w1p + (size_t)(c + 1) * kBufFloats,
+                               smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
       bc0 = bn0;
       bc1 = bn1;
       ++q;
     }
+    __syncthreads();     // last layer-1 chunk; the first layer-2 chunk streams in behind it
+    if (kLinear) {
+      mma_chunk<kNB, 512, 0>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g, nullptr, nullptr,
+                             wave_u, lane);
+    } else {
+      mma_chunk<kNB, 512, NP2>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g, d.w2p,
+                               smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+    }
+    ++q;
   }
 
   if (kLinear) {
@@ -224,14 +293,21 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
   f4 o2[kNB];
 #pragma unroll
   for (int nb = 0; nb < NB2; ++nb) o2[nb] = *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
+  {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-  for (int cc = 0; cc < kD / 32; ++cc) {
-    __syncthreads();
-    if (cc + 1 < kD / 32) {
-      stage_chunk<NP2>(d.w2p + (size_t)(cc + 1) * (8 * NP2 * 4), smem + ((q + 1) & 1) * kBufFloats, tid);
+    for (int cc = 0; cc < kD / 32; ++cc) {
+      __syncthreads();
+      if (cc + 1 < kD / 32) {
+        mma_chunk<NB2, NP2, NP2>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g,
+                                 d.w2p + (size_t)(cc + 1) * (8 * NP2 * 4),
+                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+      } else {
+        mma_chunk<NB2, NP2, 0>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g,
+                               nullptr, nullptr, wave_u, lane);
+      }
+      ++q;
     }
-    mma_chunk<NB2, NP2>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g);
-    ++q;
   }
 
   if (MODE == GC_MODE_MLP_OUT) {

@@ -32,11 +32,13 @@ LN_EPS = 1e-5   # haiku default; no in-tree override (dense.py:182-188)
 
 
 def swish(x):
-  return x / (1.0 + np.exp(-x))
+  with np.errstate(over="ignore"):      # exp(-x) -> inf gives x / inf = -0.0, the right limit
+    return x / (1.0 + np.exp(-x))
 
 
 def linear(x, w, b):
-  return x @ w + b
+  # 2-D GEMM: numpy would treat [rows, batch, k] @ [k, n] as `rows` tiny [batch, k] products
+  return (x.reshape(-1, x.shape[-1]) @ w).reshape(x.shape[:-1] + (w.shape[1],)) + b
 
 
 def mlp(x, layers):

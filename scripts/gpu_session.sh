@@ -13,7 +13,7 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log
 echo "smoke rc=$?" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
 
 echo "== pytest -m gpu (glds)" | tee -a "$OUT/summary.txt"
-timeout 1200 python -m pytest tests -m gpu -q -rA --timeout=600 > "$OUT/pytest_gpu.log" 2>&1
+timeout 1200 python -m pytest tests -m gpu -q --timeout=600 > "$OUT/pytest_gpu.log" 2>&1
 RC=$?
 echo "pytest rc=$RC" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
 if [ $RC -ne 0 ]; then
@@ -32,11 +32,11 @@ echo "bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "
 
 if [ "${DO_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel trace" | tee -a "$OUT/summary.txt"
-  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o trace -- \
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- \
       python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --op-timing-iters 1 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
   echo "rocprof rc=$?" | tee -a "$OUT/summary.txt"
-  find "$OUT/prof" -name "*stats*" | head | tee -a "$OUT/summary.txt"
-  for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do head -20 "$f" | tee -a "$OUT/summary.txt"; done
+  find "$OUT/prof" -type f | head | tee -a "$OUT/summary.txt"
+  for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do head -12 "$f" | cut -c1-220 | tee -a "$OUT/summary.txt"; done
   # keep only the small summaries (the raw trace can be large)
   find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 fi
