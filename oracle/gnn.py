@@ -107,13 +107,18 @@ def _edge_update(net, name, edge, nodes, chunk):
 
 def deep_typed_graph_net(params, gnn_name, graph, *, num_steps, embed_nodes,
                          embed_edges, node_output=(), dtype=np.float64,
-                         chunk=1 << 16, live_nodes=None, live_edges=None):
+                         chunk=1 << 16, live_nodes=None, live_edges=None,
+                         f32_aggregation=False):
   """Returns {"nodes": {...}, "edges": {...}} of output features.
 
   ``live_nodes`` / ``live_edges`` optionally restrict which outputs are computed
   on the LAST step (the reference computes everything; GraphCast only reads
   some of it -- ``graphcast.py:602-603,639,676``).  Results that are computed
   are identical either way.
+
+  ``f32_aggregation`` restates ``deep_typed_graph_net.py:273-281``: the edge messages are
+  cast to float32 around the segment-sum and the result cast back (an up-cast for the
+  reference's bf16 activations, a no-op in fp32, a DOWN-cast when the oracle runs in float64).
   """
   net = Net(params, gnn_name, dtype)
   nodes = {k: np.asarray(v, dtype=dtype) for k, v in graph["nodes"].items()}
@@ -137,7 +142,8 @@ def deep_typed_graph_net(params, gnn_name, graph, *, num_steps, embed_nodes,
     for k, h in nodes.items():
       if last and live_nodes is not None and k not in live_nodes:
         continue
-      received = [segment_sum(new_edges[ek], e["receivers"], h.shape[0])
+      agg_in = (lambda a: a.astype(np.float32)) if f32_aggregation else (lambda a: a)
+      received = [segment_sum(agg_in(new_edges[ek]), e["receivers"], h.shape[0]).astype(dtype)
                   for ek, e in sorted(edges.items()) if e["receivers_set"] == k]
       new_nodes[k] = net.apply(f"processor_nodes_{step}_{k}", h, *received)
     for k in list(nodes):

@@ -49,8 +49,12 @@ def _batch(x, b, dtype):
 
 
 def forward(params, graphs, x_grid, steps, dtype=np.float64, chunk=1 << 16,
-            return_latents=False):
-  """x_grid [N_grid, B, C_in] -> [N_grid, B, C_out]."""
+            return_latents=False, f32_aggregation=False):
+  """x_grid [N_grid, B, C_in] -> [N_grid, B, C_out].
+
+  ``f32_aggregation=True`` reproduces the reference's float32 cast around the grid2mesh
+  segment-sum (``graphcast.py:215``); it only changes results when ``dtype`` is float64 and is
+  used to match the golden vectors bit-for-bit.  The float64 "truth" for GPU parity leaves it off."""
   x = np.asarray(x_grid, dtype=dtype)
   b = x.shape[1]
   n_mesh = graphs["n_mesh"]
@@ -66,7 +70,7 @@ def forward(params, graphs, x_grid, steps, dtype=np.float64, chunk=1 << 16,
            senders=graphs["g2m"]["senders"], receivers=graphs["g2m"]["receivers"],
            features=_batch(graphs["g2m"]["feat"], b, dtype))}},
       num_steps=1, embed_nodes=True, embed_edges=True, dtype=dtype, chunk=chunk,
-      live_edges=())
+      live_edges=(), f32_aggregation=f32_aggregation)
   lat_mesh, lat_grid = enc["nodes"]["mesh_nodes"], enc["nodes"]["grid_nodes"]
   # mesh (:606-639)
   proc = gnn.deep_typed_graph_net(

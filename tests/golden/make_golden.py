@@ -12,9 +12,21 @@ What runs unmodified from /root/reference/weathernext (numpy/scipy only):
   absent from this image; inert stand-ins are placed in ``sys.modules`` so the
   ``import`` lines succeed -- none of the executed functions touch them.
 
+Part 2 executes the reference's GNN sources UNMODIFIED --
+  weathernext1_graph/graphcast.py (GraphCast.__init__, _init_*_graph, _run_grid2mesh_gnn,
+  _run_mesh_gnn, _run_mesh2grid_gnn), utils/legacy/deep_typed_graph_net.py,
+  utils/typed_graph_net.py, utils/typed_graph.py -- on the numpy stand-ins for
+  haiku / jraph / jax / chex in tests/golden/ref_shims (see its README: this pins the
+  reference's WIRING and parameter tree; the primitives are restated from the libraries'
+  published behaviour).  trimesh is absent, so grid_mesh_connectivity.in_mesh_triangle_indices
+  is replaced by the oracle's containing-triangle query for this run (its output is part
+  of the fixture).
+
 Outputs
   structure_tiny.npz   every structure array for a 10 deg grid / M2 mesh
   structure_hashes.json  sha256 fingerprints (+ counts) for 1 deg/M5 and 0.25 deg/M6
+  gnn_tiny.npz         10 deg / M2, latent 32, 2 processor steps, batch 2: parameter tree
+                       ("params:<module>:<leaf>"), input x, the three stage outputs, float64
 """
 import hashlib
 import json
@@ -91,6 +103,91 @@ def reference_structure(res, mesh_size, fraction=0.6):
               grid_xyz=gmc._grid_lat_lon_to_coordinates(lat, lon))
 
 
+def params_digest(params):
+  """sha256 over the sorted parameter leaves (detects drift of a seed-regenerated tree)."""
+  h = hashlib.sha256()
+  for mod in sorted(params):
+    for leaf in sorted(params[mod]):
+      h.update(f"{mod}:{leaf}".encode())
+      h.update(np.ascontiguousarray(params[mod][leaf], dtype=np.float32).tobytes())
+  return h.hexdigest()
+
+
+def reference_gnn(res=10.0, mesh_size=2, latent=32, steps=2, batch=2, c_in=17, seed=5,
+                  params=None):
+  """Runs the reference GraphCast's three DeepTypedGraphNets on the haiku/jraph/jax stand-ins."""
+  import typing
+  import typing_extensions
+  for n in ("Required", "NotRequired"):          # reference targets python >= 3.11
+    if not hasattr(typing, n):
+      setattr(typing, n, getattr(typing_extensions, n))
+  if not getattr(reference_gnn, "_shims_installed", False):
+    for name in [m for m in sys.modules if m.split(".")[0] in ("jax", "haiku", "jraph", "chex")]:
+      del sys.modules[name]                      # drop part 1's inert stand-ins
+    sys.path.insert(0, os.path.join(HERE, "ref_shims"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))   # repo root, for `oracle`
+    for name in [m for m in sys.modules if m.startswith("weathernext.") and
+                 m.split(".")[-1] in ("typed_graph_net", "deep_typed_graph_net", "dense",
+                                      "model_utils")]:
+      del sys.modules[name]                      # re-import on top of the numpy stand-ins
+    reference_gnn._shims_installed = True
+  import haiku as hk
+  from weathernext.utils.legacy import grid_mesh_connectivity as gmc
+  from weathernext.weathernext1_graph import graphcast as rgc
+  from oracle import connectivity as oconn
+
+  def m2g(*, grid_latitude, grid_longitude, mesh):
+    return oconn.containing_triangle_query(grid_latitude, grid_longitude, mesh.vertices, mesh.faces)
+  gmc.in_mesh_triangle_indices = m2g
+  rgc.grid_mesh_connectivity.in_mesh_triangle_indices = m2g
+
+  lat = np.arange(-90, 90 + res / 2, res).astype(np.float32)
+  lon = np.arange(0, 360, res).astype(np.float32)
+  cfg = rgc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=latent,
+                        gnn_msg_steps=steps, hidden_layers=1,
+                        radius_query_fraction_edge_length=0.6)
+  rng = np.random.default_rng(seed)
+  x = rng.standard_normal((len(lat) * len(lon), batch, c_in)).astype(np.float32).astype(np.float64)
+  given = params is not None
+  params = params if given else {}
+
+  def run(model):
+    lm, lg = model._run_grid2mesh_gnn(x)
+    um = model._run_mesh_gnn(lm)
+    return lm, lg, um, model._run_mesh2grid_gnn(um, lg)
+
+  def build():
+    model = rgc.GraphCast(cfg, rgc.TASK_13)
+    model._init_mesh_properties()
+    model._init_grid_properties(grid_lat=lat, grid_lon=lon)
+    model._grid2mesh_graph_structure = model._init_grid2mesh_graph()
+    model._mesh_graph_structure = model._init_mesh_graph()
+    model._mesh2grid_graph_structure = model._init_mesh2grid_graph()
+    return model
+
+  if not given:
+    with hk.running(params, init_rng=rng):       # creates the parameter tree (haiku-default init)
+      run(build())
+    for leaves in params.values():               # make b / scale / offset non-trivial
+      for k in leaves:
+        if k in ("b", "offset"):
+          leaves[k] = (0.1 * rng.standard_normal(leaves[k].shape)).astype(np.float32)
+        elif k == "scale":
+          leaves[k] = (1.0 + 0.1 * rng.standard_normal(leaves[k].shape)).astype(np.float32)
+  with hk.running(params):                       # no rng: every parameter must already exist
+    model = build()
+    lm, lg, um, out = run(model)
+  g2m = model._grid2mesh_graph_structure.edge_by_name("grid2mesh")
+  m2g_e = model._mesh2grid_graph_structure.edge_by_name("mesh2grid")
+  fx = ({} if given else
+        {f"params:{mod}:{leaf}": v for mod, leaves in params.items() for leaf, v in leaves.items()})
+  fx.update(lat=lat, lon=lon, x=x, latent_mesh=lm, latent_grid=lg, updated_mesh=um, out=out,
+            g2m_senders=g2m.indices.senders, g2m_receivers=g2m.indices.receivers,
+            m2g_senders=m2g_e.indices.senders, m2g_receivers=m2g_e.indices.receivers,
+            config=np.array([res, mesh_size, latent, steps, batch, c_in], dtype=np.float64))
+  return fx
+
+
 def main():
   _install_inert_modules()
   sys.path.insert(0, REF)
@@ -114,6 +211,23 @@ def main():
     print(tag, {k: entry[k]["shape"] for k in st})
   with open(os.path.join(HERE, "structure_hashes.json"), "w") as f:
     json.dump(hashes, f, indent=1, sort_keys=True)
+  if "--skip-gnn" not in sys.argv:
+    fx = reference_gnn()
+    np.savez_compressed(os.path.join(HERE, "gnn_tiny.npz"), **fx)
+    print("gnn_tiny:", fx["out"].shape, len([k for k in fx if k.startswith("params:")]), "leaves")
+    # latent 512 (what the HIP kernels are built for): the 8.7 M parameters are regenerated
+    # from a seed by oracle.params.init_params on both sides; their digest is in the fixture.
+    from oracle import params as oparams
+    c_in, c_out, steps, seed = 183, 83, 2, 1
+    p512 = oparams.init_params(c_in, c_out, 512, steps, seed=seed, nontrivial=True)
+    fx = reference_gnn(latent=512, steps=steps, batch=1, c_in=c_in, seed=11, params=p512)
+    keep = {k: fx[k] for k in ("lat", "lon", "out", "config")}
+    keep["x"] = fx["x"].astype(np.float32)
+    keep["latent_mesh_checksum"] = np.array([fx["latent_mesh"].sum(), np.abs(fx["updated_mesh"]).sum()])
+    keep["params_seed"] = np.array([c_in, c_out, 512, steps, seed])
+    keep["params_sha256"] = np.array(params_digest(p512))
+    np.savez_compressed(os.path.join(HERE, "gnn_latent512.npz"), **keep)
+    print("gnn_latent512:", keep["out"].shape, str(keep["params_sha256"])[:16])
 
 
 if __name__ == "__main__":

@@ -173,6 +173,24 @@ class Sequential(Module):
     return x
 
 
+class initializers:  # noqa: N801
+  """hk.initializers names used in annotations / defaults of imported code."""
+  Initializer = object
+
+  @staticmethod
+  def TruncatedNormal(stddev=1.0, mean=0.0):  # noqa: N802
+    return _truncated_normal(stddev)
+
+  @staticmethod
+  def Constant(v):  # noqa: N802
+    return _constant(v)
+
+
+def name_like(method_name):
+  """hk.name_like: only decorates methods of modules that are imported but never run here."""
+  return lambda f: f
+
+
 def remat(f, *a, **k):
   return f
 

@@ -1,6 +1,7 @@
 """jax stand-in on numpy: tree utilities, jax.nn activations, no-op jit/device_get."""
 import numpy as _np
 
+from . import lax  # noqa: F401
 from . import numpy  # noqa: F401
 from . import tree_util  # noqa: F401
 from . import tree_util as tree  # noqa: F401  (jax.tree.map / flatten / unflatten)

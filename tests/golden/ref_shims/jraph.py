@@ -12,6 +12,7 @@ import numpy as np
 import jax.tree_util as _tree
 
 ArrayTree = Any
+GraphsTuple = Any
 NodeFeatures = EdgeFeatures = Globals = SenderFeatures = ReceiverFeatures = Any
 AggregateEdgesToNodesFn = AggregateNodesToGlobalsFn = AggregateEdgesToGlobalsFn = Callable
 GNUpdateEdgeFn = GNUpdateNodeFn = GNUpdateGlobalFn = InteractionUpdateEdgeFn = Callable

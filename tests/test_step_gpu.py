@@ -81,3 +81,20 @@ def test_missing_params_and_bad_shapes_raise(small):
     empty.forward_grid_node_features(torch.zeros((4, 1, 183), device="cuda:0"))
   with pytest.raises(ValueError):
     small["model"].forward_grid_node_features(torch.zeros((5, 1, 183), device="cuda:0"))
+
+
+def test_step_matches_reference_golden_vectors(golden_dir):
+  """HIP path vs tests/golden/gnn_latent512.npz = the reference's own graphcast.py /
+  deep_typed_graph_net.py / typed_graph_net.py executed (float64) on numpy stand-ins for
+  haiku / jraph / jax (tests/golden/make_golden.py).  fp32 tolerance: rel-RMSE <= 2e-5."""
+  from tests.test_oracle_gnn_golden import load_latent512
+  z, params, steps = load_latent512(golden_dir)
+  res, mesh_size = float(z["config"][0]), int(z["config"][1])
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=steps,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(z["lat"], z["lon"])
+  y = model.forward_grid_node_features(torch.from_numpy(z["x"]).to("cuda:0"))
+  torch.cuda.synchronize()
+  err = rel_rmse(y.cpu().numpy(), z["out"])
+  print(f"step rel-RMSE vs reference-executed golden vectors: {err:.3e}")
+  assert err <= REL_RMSE_TOL
