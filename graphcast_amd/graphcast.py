@@ -40,10 +40,10 @@ FORCING_VARS = variables.EXTERNAL_FORCING_VARS + variables.TIME_FORCING_VARS
 @dataclasses.dataclass(frozen=True, eq=True)
 class TaskConfig:
   """Inputs / targets of a task (reference ``utils/task.py:20-29``)."""
-  input_variables: tuple
-  target_variables: tuple
-  forcing_variables: tuple
-  pressure_levels: tuple
+  input_variables: tuple[str, ...]
+  target_variables: tuple[str, ...]
+  forcing_variables: tuple[str, ...]
+  pressure_levels: tuple[int, ...]
   input_duration: str
 
 
@@ -74,7 +74,7 @@ class ModelConfig:
 
 @dataclasses.dataclass(frozen=True, eq=True)
 class CheckPoint:
-  params: dict
+  params: dict[str, Any]
   model_config: ModelConfig
   task_config: TaskConfig
   description: str
@@ -251,30 +251,38 @@ class GraphCast(predictor_base.Predictor):
 
   # ---------------------------------------------------------------- Dataset boundary
   def __call__(self, inputs, targets_template, forcings, is_training: bool = False):
-    from graphcast_amd import xarray_lite as xl
+    """Reference :298-329.  ``inputs`` / ``forcings`` may hold numpy arrays (host datasets:
+    one H2D of the stacked features, one D2H of the outputs) or torch tensors already on the
+    device (rollouts that keep the state in HBM: nothing crosses PCIe)."""
+    del is_training
     import torch
-    self._maybe_init(np.asarray(inputs.coords["lat"]), np.asarray(inputs.coords["lon"]))
+    self._maybe_init(np.asarray(inputs.coords["lat"].values), np.asarray(inputs.coords["lon"].values))
     features = self._inputs_to_grid_node_features(inputs, forcings)
-    x = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(self._device)
+    on_device = torch.is_tensor(features)
+    if on_device:
+      x = features.to(device=self._device, dtype=torch.float32).contiguous()
+    else:
+      x = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(self._device)
     y = self.forward_grid_node_features(x)
-    return self._grid_node_outputs_to_prediction(y.cpu().numpy(), targets_template)
+    return self._grid_node_outputs_to_prediction(y if on_device else y.cpu().numpy(),
+                                                 targets_template)
 
-  def _inputs_to_grid_node_features(self, inputs, forcings) -> np.ndarray:
+  def _inputs_to_grid_node_features(self, inputs, forcings):
     """Datasets -> [num_grid_nodes, batch, num_channels] (reference :680-699)."""
     from graphcast_amd import xarray_lite as xl
     stacked_inputs = model_utils.dataset_to_stacked(inputs)
     stacked_forcings = model_utils.dataset_to_stacked(forcings)
     stacked = xl.concat([stacked_inputs, stacked_forcings], dim="channels")
-    leading = model_utils.lat_lon_to_leading_axes(stacked)
-    data = np.asarray(leading.data)
-    return data.reshape((-1,) + data.shape[2:])
+    data = model_utils.lat_lon_to_leading_axes(stacked).data
+    return data.reshape((-1,) + tuple(data.shape[2:]))
 
-  def _grid_node_outputs_to_prediction(self, grid_node_outputs: np.ndarray, targets_template):
+  def _grid_node_outputs_to_prediction(self, grid_node_outputs, targets_template):
     """[num_grid_nodes, batch, num_outputs] -> Dataset (reference :701-723)."""
     from graphcast_amd import xarray_lite as xl
     grid_shape = (self._grid_lat.shape[0], self._grid_lon.shape[0])
-    leading = xl.DataArray(grid_node_outputs.reshape(grid_shape + grid_node_outputs.shape[1:]),
-                           dims=("lat", "lon", "batch", "channels"))
+    leading = xl.DataArray(
+        grid_node_outputs.reshape(grid_shape + tuple(grid_node_outputs.shape[1:])),
+        dims=("lat", "lon", "batch", "channels"))
     restored = model_utils.restore_leading_axes(leading)
     return model_utils.stacked_to_dataset(restored.variable, targets_template)
 

@@ -134,3 +134,76 @@ def get_bipartite_graph_spatial_features(
   else:
     e_feat = np.zeros([senders.shape[0], 0], dtype=dtype)
   return s_feat, r_feat, e_feat
+
+
+# ----------------------------------------------------------------------------- Dataset <-> stacked
+_PRESERVED = ("batch", "lat", "lon")
+
+
+def lat_lon_to_leading_axes(grid_xarray):
+  """[...] + (lat, lon) + [...] -> (lat, lon, ...)  (reference :155-161)."""
+  return grid_xarray.transpose("lat", "lon", ...)
+
+
+def restore_leading_axes(grid_xarray):
+  """(lat, lon, [batch, time, level], ...) -> ([batch, time, level], lat, lon, ...)  (reference :164-177)."""
+  dims = list(grid_xarray.dims)
+  front = [d for d in ("batch", "time", "level") if d in dims]
+  return grid_xarray.transpose(*(front + [d for d in dims if d not in front]))
+
+
+def variable_to_stacked(variable, sizes: Mapping[str, int],
+                        preserved_dims: Tuple[str, ...] = _PRESERVED):
+  """Variable -> preserved_dims + ("channels",)  (reference :645-674).
+
+  Every dim outside ``preserved_dims`` is folded (C order, i.e. time-major then level)
+  into a trailing ``channels`` dim; missing preserved dims are broadcast to ``sizes``."""
+  folded = [d for d in variable.dims if d not in preserved_dims]
+  if folded:
+    variable = variable.stack(channels=folded)
+  out_sizes = {d: variable.sizes.get(d) or sizes[d] for d in preserved_dims}
+  out_sizes["channels"] = variable.sizes.get("channels", 1)
+  return variable.set_dims(out_sizes)
+
+
+def dataset_to_stacked(dataset, sizes: Optional[Mapping[str, int]] = None,
+                       preserved_dims: Tuple[str, ...] = _PRESERVED):
+  """Dataset -> one DataArray preserved_dims + ("channels",), variables in sorted-name
+  order (reference :677-710)."""
+  from graphcast_amd import xarray_lite as xr
+  sizes = sizes or dataset.sizes
+  variables = dataset.variables
+  stacked = [variable_to_stacked(variables[name], sizes, preserved_dims)
+             for name in sorted(dataset.data_vars.keys())]
+  coords = {d: c for d, c in dataset.coords.items() if d in preserved_dims}
+  return xr.DataArray(data=xr.Variable.concat(stacked, dim="channels"), coords=coords)
+
+
+def stacked_to_dataset(stacked_array, template_dataset,
+                       preserved_dims: Tuple[str, ...] = _PRESERVED):
+  """Inverse of ``dataset_to_stacked`` given a template (reference :713-776)."""
+  from graphcast_amd import xarray_lite as xr
+  names = sorted(template_dataset.keys())
+  unstack_sizes = {}
+  for name in names:
+    tv = template_dataset[name]
+    if not all(d in tv.dims for d in preserved_dims):
+      raise ValueError(
+          f"stacked_to_dataset requires all Variables to have {preserved_dims} "
+          f"dimensions, but found only {tv.dims}.")
+    unstack_sizes[name] = {d: n for d, n in tv.sizes.items() if d not in preserved_dims}
+  channels = {name: int(np.prod(list(s.values()), dtype=np.int64))
+              for name, s in unstack_sizes.items()}
+  expected, found = sum(channels.values()), stacked_array.sizes["channels"]
+  if expected != found:
+    raise ValueError(
+        f"Expected {expected} channels but found {found}, when trying to convert a stacked "
+        f"array of shape {stacked_array.sizes} to a dataset of shape {template_dataset}.")
+  data_vars, start = {}, 0
+  for name in names:
+    tv = template_dataset[name]
+    piece = stacked_array.isel({"channels": slice(start, start + channels[name])})
+    start += channels[name]
+    piece = piece.unstack({"channels": unstack_sizes[name]}).transpose(*tv.dims)
+    data_vars[name] = xr.DataArray(data=piece, coords=dict(tv._coords), name=tv.name)
+  return type(template_dataset)(data_vars)

@@ -1,0 +1,300 @@
+"""Chunked autoregressive rollouts: drop-in for ``weathernext/utils/rollout.py``.
+
+Same public names, arguments and error behaviour as the reference
+(``chunked_prediction`` :326-364, ``chunked_prediction_generator`` :367-565,
+``chunked_prediction_generator_multiple_runs`` :158-307, ``_get_next_inputs``
+:581-604, ``extend_targets_template`` :618-658): the predictor is called **by
+keyword** with ``rng, inputs, targets_template, forcings``; every chunk sees the
+time coordinates of the first chunk (relative lead times); ``datetime``
+coordinates are stripped before the loop and re-attached to the predictions.
+
+What differs, MI355X-first:
+
+* There is no jit / pmap.  The rolling-window update (``_get_next_inputs``) is a
+  handful of container operations on ``xarray_lite`` objects whose ``data`` may
+  be torch tensors resident in HBM -- the 2-frame state never has to leave the
+  device between steps (``device_put_fn`` moves it there once).
+* ``pmap_devices`` (one ensemble member per local device driven from one
+  process) becomes *one process per GPU*: ``chunked_prediction_generator_multiple_runs``
+  takes ``rank`` / ``world_size`` and rolls out only the members this rank owns
+  (member ``i`` -> rank ``i % world_size``, see ``ensemble.py``); there is no
+  collective inside a step.  Passing ``pmap_devices`` raises with that message.
+* ``rng`` is opaque to this module (GraphCast is deterministic): it is split with
+  ``split_rng`` -- numpy ``SeedSequence`` spawning for ints / SeedSequences, pass
+  through for ``None`` -- and handed to the predictor unchanged otherwise.
+"""
+import logging
+from typing import Any, Callable, Iterator, Optional, Protocol, Sequence
+
+import numpy as np
+
+from graphcast_amd import xarray_lite as xarray
+
+log = logging.getLogger(__name__)
+
+
+class PredictorFn(Protocol):
+  """Functional version of ``Predictor.__call__`` with an explicit rng (reference :78-87)."""
+
+  def __call__(self, rng: Any, inputs: xarray.Dataset, targets_template: xarray.Dataset,
+               forcings: Optional[xarray.Dataset], **optional_kwargs) -> xarray.Dataset:
+    ...
+
+
+# ----------------------------------------------------------------------------- rng
+def split_rng(rng):
+  """(carry, this_step) -- the role of ``_split_rng_fn`` (reference :568-578)."""
+  if rng is None:
+    return None, None
+  if isinstance(rng, (int, np.integer)):
+    rng = np.random.SeedSequence(int(rng))
+  if isinstance(rng, np.random.SeedSequence):
+    a, b = rng.spawn(2)
+    return a, b
+  return rng, rng        # opaque key owned by the caller's predictor
+
+
+# ----------------------------------------------------------------------------- next inputs
+def _get_next_inputs(prev_inputs: xarray.Dataset, next_frame: xarray.Dataset) -> xarray.Dataset:
+  """Rolling window: drop the oldest frame, append the new one (reference :581-604)."""
+  non_predicted_or_forced_inputs = [k for k in prev_inputs.keys() if k not in next_frame.keys()]
+  for k in non_predicted_or_forced_inputs:
+    if "time" in prev_inputs[k].dims:
+      raise ValueError("Found an input with a time index that is not predicted or forced.")
+  next_inputs_keys = [k for k in next_frame.keys() if k in prev_inputs.keys()]
+  next_inputs = next_frame[next_inputs_keys]
+  num_inputs = prev_inputs.sizes["time"]
+  return xarray.concat([prev_inputs, next_inputs], dim="time", data_vars="different",
+                       compat="equals").tail(time=num_inputs)
+
+
+# ----------------------------------------------------------------------------- generator
+def chunked_prediction_generator(
+    predictor_fn: PredictorFn,
+    rng: Any,
+    inputs: xarray.Dataset,
+    targets_template: xarray.Dataset,
+    num_steps_per_chunk: int,
+    forcings: Optional[xarray.Dataset] = None,
+    verbose: bool = False,
+    pmap_devices: Optional[Sequence[Any]] = None,
+    replica_axis: Optional[str] = None,
+    device_put_fn: Optional[Callable[[xarray.Dataset], xarray.Dataset]] = None,
+    replicate_fn: Optional[Callable[[xarray.Dataset], xarray.Dataset]] = None,
+) -> Iterator[xarray.Dataset]:
+  """Yields the predictions of each chunk of a chunked rollout (reference :367-565)."""
+  if pmap_devices is not None:
+    raise ValueError(
+        "pmap_devices is a single-process multi-device feature of the reference; this build runs "
+        "one process per GPU: use chunked_prediction_generator_multiple_runs(rank=, world_size=).")
+  if (replicate_fn is None) ^ (replica_axis is None):
+    raise ValueError("Must provide replicate_fn when replica_axis is provided.")
+
+  if forcings is None:
+    # (the reference iterates `.coords` keys here and cannot unpack them)
+    forcings = xarray.Dataset({}, coords={
+        n: c for n, c in targets_template.coords.items() if "time" in c.dims})
+
+  # Copies: never mutate the caller's datasets.
+  inputs = inputs.copy()
+  targets_template = targets_template.copy()
+  forcings = forcings.copy()
+
+  if "datetime" in inputs.coords:
+    del inputs.coords["datetime"]
+  if "datetime" in targets_template.coords:
+    output_datetime = targets_template.coords["datetime"]
+    del targets_template.coords["datetime"]
+  else:
+    output_datetime = None
+  if "datetime" in forcings.coords:
+    del forcings.coords["datetime"]
+
+  num_target_steps = targets_template.sizes["time"]
+  num_chunks, remainder = divmod(num_target_steps, num_steps_per_chunk)
+  if remainder != 0:
+    raise ValueError(
+        f"The number of steps per chunk {num_steps_per_chunk} must "
+        f"evenly divide the number of target steps {num_target_steps} ")
+  if len(np.unique(np.diff(np.asarray(targets_template.coords["time"].values)))) > 1:
+    raise ValueError("The targets time coordinates must be evenly spaced")
+
+  # Every chunk is presented with the time coordinates of the first chunk.
+  chunk_inputs_time_array = inputs.coords["time"].values
+  chunk_targets_time_array = targets_template.isel(
+      time=slice(0, num_steps_per_chunk)).coords["time"].values
+
+  current_inputs = inputs
+  if replicate_fn is not None:
+    current_inputs = replicate_fn(current_inputs)
+  if device_put_fn is not None:
+    current_inputs = device_put_fn(current_inputs)
+  del inputs
+
+  for chunk_index in range(num_chunks):
+    if verbose:
+      log.info("Chunk %d/%d", chunk_index, num_chunks)
+    target_offset = num_steps_per_chunk * chunk_index
+    target_slice = slice(target_offset, target_offset + num_steps_per_chunk)
+    current_targets_template = targets_template.isel(time=target_slice).compute()
+    current_forcings = forcings.isel(time=target_slice).compute()
+
+    time_coords_to_override = {
+        n: c for n, c in current_targets_template.coords.items() if "time" in c.dims}
+
+    if replicate_fn is not None:
+      current_forcings = replicate_fn(current_forcings)
+      current_targets_template = replicate_fn(current_targets_template)
+    if device_put_fn is not None:
+      current_forcings = device_put_fn(current_forcings)
+      current_targets_template = device_put_fn(current_targets_template)
+
+    rng, this_rng = split_rng(rng)
+
+    current_inputs = current_inputs.assign_coords(time=chunk_inputs_time_array)
+    current_forcings = current_forcings.assign_coords(time=chunk_targets_time_array)
+    current_targets_template = current_targets_template.assign_coords(time=chunk_targets_time_array)
+    predictions = predictor_fn(
+        rng=this_rng, inputs=current_inputs, targets_template=current_targets_template,
+        forcings=current_forcings)
+    del current_targets_template
+
+    if chunk_index == num_chunks - 1:
+      current_inputs = None
+    else:
+      next_frame = predictions.assign(current_forcings)
+      current_inputs = _get_next_inputs(current_inputs, next_frame)
+      del next_frame
+    del current_forcings
+
+    predictions = predictions.assign_coords(time_coords_to_override)
+    if output_datetime is not None:
+      predictions.coords["datetime"] = output_datetime.isel(time=target_slice)
+    yield predictions
+    del predictions
+
+
+def _to_host(ds: xarray.Dataset) -> xarray.Dataset:
+  """``jax.device_get`` of the reference (:362): torch-backed variables -> numpy."""
+  def get(v):
+    data = v.data
+    if xarray._is_torch(data):
+      data = data.detach().cpu().numpy()
+    return xarray.Variable(v.dims, data)
+  return xarray.Dataset._construct({k: get(v) for k, v in ds._vars.items()},
+                                   {k: get(v) for k, v in ds._coords.items()})
+
+
+def chunked_prediction(
+    predictor_fn: PredictorFn,
+    rng: Any,
+    inputs: xarray.Dataset,
+    targets_template: xarray.Dataset,
+    forcings: Optional[xarray.Dataset] = None,
+    num_steps_per_chunk: int = 1,
+    **kwargs,
+) -> xarray.Dataset:
+  """Long trajectory by concatenating chunked predictions in time (reference :326-364)."""
+  chunks_list = []
+  for prediction_chunk in chunked_prediction_generator(
+      predictor_fn=predictor_fn, rng=rng, inputs=inputs, targets_template=targets_template,
+      forcings=forcings, num_steps_per_chunk=num_steps_per_chunk, **kwargs):
+    chunks_list.append(_to_host(prediction_chunk))
+    del prediction_chunk
+  return xarray.concat(chunks_list, dim="time")
+
+
+# ----------------------------------------------------------------------------- ensembles
+def _slice_sample_if_present(inputs, forcings, sample_idx):
+  """reference :313-323."""
+  if "sample" in inputs.dims:
+    inputs = inputs.isel(sample=sample_idx)
+  if forcings is not None and "sample" in forcings.dims:
+    forcings = forcings.isel(sample=sample_idx)
+  return inputs, forcings
+
+
+def chunked_prediction_generator_multiple_runs(
+    predictor_fn: PredictorFn,
+    rngs: Sequence[Any],
+    inputs: xarray.Dataset,
+    targets_template: xarray.Dataset,
+    forcings: Optional[xarray.Dataset],
+    num_samples: Optional[int],
+    pmap_devices: Optional[Sequence[Any]] = None,
+    rank: int = 0,
+    world_size: int = 1,
+    **chunked_prediction_kwargs,
+) -> Iterator[xarray.Dataset]:
+  """Rolls out several ensemble members (reference :158-307).
+
+  All lead-time chunks of one member are yielded before the next member starts, each
+  carrying the scalar coordinate ``sample`` = member index, exactly as the reference's
+  un-pmapped branch (:286-307).  With ``world_size`` > 1 (one process per GPU) this rank
+  only rolls out members ``rank, rank + world_size, ...``: members never interact, so
+  there is no collective (``ensemble.gather_member_chunks`` collects results if wanted).
+  """
+  if pmap_devices is not None:
+    raise ValueError("pmap_devices is not supported: launch one process per GPU and pass "
+                     "rank= / world_size= instead.")
+  if num_samples is None:
+    if "sample" not in inputs.dims:
+      raise ValueError(
+          "The number of samples must be passed when `inputs` don't have a `sample` dim.")
+    num_samples = inputs.sizes["sample"]
+  if "sample" in inputs.dims and num_samples != inputs.sizes["sample"]:
+    raise ValueError(
+        f"Inconsistent number of samples requested for inputs{num_samples} != "
+        f"{inputs.sizes['sample']}.")
+  if num_samples != len(rngs):
+    raise ValueError(f"Inconsistent number of rngs passed. {num_samples} != {len(rngs)}.")
+  if forcings:
+    if "sample" in forcings.dims and num_samples != forcings.sizes["sample"]:
+      raise ValueError(
+          f"Inconsistent number of samples requested for forcings{num_samples} != "
+          f"{forcings.sizes['sample']}.")
+  if not 0 <= rank < world_size:
+    raise ValueError(f"rank {rank} outside world of size {world_size}")
+
+  for i in range(rank, num_samples, world_size):
+    log.info("Sample %d/%d", i, num_samples)
+    sample_inputs, sample_forcings = _slice_sample_if_present(inputs, forcings, sample_idx=i)
+    for prediction_chunk in chunked_prediction_generator(
+        predictor_fn, rngs[i], inputs=sample_inputs, targets_template=targets_template,
+        forcings=sample_forcings, **chunked_prediction_kwargs):
+      prediction_chunk.coords["sample"] = xarray.Variable((), np.asarray(i))
+      yield prediction_chunk
+    log.info("Completed sample %d/%d", i, num_samples)
+
+
+def extend_targets_template(targets_template: xarray.Dataset, required_num_steps: int,
+                            value: Optional[float] = None) -> xarray.Dataset:
+  """Template of ``required_num_steps`` equispaced lead times (reference :618-690).
+
+  The reference fills it with lazy dask arrays; here the data are zero-stride broadcasts of
+  one scalar (``value`` or 0), so nothing of the extended size is ever allocated."""
+  time = np.asarray(targets_template.coords["time"].values)
+  timestep = time[0]
+  if time.shape[0] > 1:
+    assert np.all(timestep == time[1:] - time[:-1])
+  extended_time = (np.arange(required_num_steps) + 1) * timestep
+  coords = {k: v for k, v in targets_template._coords.items() if "time" not in v.dims}
+  coords["time"] = xarray.Variable(("time",), extended_time)
+  if "datetime" in targets_template.coords:
+    datetime = np.asarray(targets_template.coords["datetime"].values)
+    coords["datetime"] = xarray.Variable(("time",), (datetime[0] - timestep) + extended_time)
+
+  def extend_time(v: xarray.Variable) -> xarray.Variable:
+    if "time" not in v.dims:
+      return v
+    shape = tuple(required_num_steps if d == "time" else n for d, n in zip(v.dims, v.shape))
+    if xarray._is_torch(v.data):
+      import torch
+      fill = torch.full((), 0.0 if value is None else value, dtype=v.data.dtype,
+                        device=v.data.device)
+      return xarray.Variable(v.dims, fill.expand(*shape))
+    fill = np.full((), 0 if value is None else value, dtype=v.dtype)
+    return xarray.Variable(v.dims, np.broadcast_to(fill, shape))
+
+  return xarray.Dataset._construct(
+      {k: extend_time(v) for k, v in targets_template._vars.items()}, coords)

@@ -73,6 +73,8 @@ def _astype(a, dtype):
     if not isinstance(dtype, torch.dtype):
       dtype = getattr(torch, np.dtype(dtype).name)
     return a.to(dtype)
+  if type(dtype).__module__.split(".")[0] == "torch":      # numpy data, torch dtype requested
+    dtype = np.dtype(str(dtype).split(".")[-1])
   return a.astype(dtype)
 
 

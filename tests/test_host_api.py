@@ -1,0 +1,372 @@
+"""CPU tests of the host-side mirror of the reference API around the step:
+Dataset <-> [node, batch, channel] stacking (model_utils.py:155-177,645-776),
+rollout.py:326-604, autoregressive.py:114-222, normalization.py:29-160,
+checkpoint.py round trip (checkpoint_test.py:65-120), ensemble member sharding.
+
+The one-step predictor used here is a tiny deterministic numpy function of the
+stacked inputs behind the Predictor interface: the device step has its own GPU
+parity tests; these tests pin the plumbing (channel order, rolling window,
+coordinates, error behaviour) that the reference leaves untested."""
+import io
+import dataclasses
+from typing import Any, Optional
+
+import numpy as np
+import pytest
+
+from graphcast_amd import autoregressive
+from graphcast_amd import checkpoint
+from graphcast_amd import ensemble
+from graphcast_amd import graphcast as gc
+from graphcast_amd import model_utils
+from graphcast_amd import normalization
+from graphcast_amd import predictor_base
+from graphcast_amd import rollout
+from graphcast_amd import synthetic
+from graphcast_amd import xarray_lite as xarray
+
+LAT = np.arange(-90, 91, 30.0)
+LON = np.arange(0, 360, 45.0)
+TASK = dataclasses.replace(gc.TASK_13, pressure_levels=(500, 850, 1000))
+
+
+class ToyStep(predictor_base.Predictor):
+  """y[c] = tanh(sum_k x[k] * A[k, c]) on the stacked channels (any backend)."""
+
+  def __init__(self, c_in, c_out, seed=3):
+    self.a = (np.random.default_rng(seed).standard_normal((c_in, c_out)) / np.sqrt(c_in)).astype(np.float32)
+    self.calls = 0
+
+  def __call__(self, inputs, targets_template, forcings, **kw):
+    self.calls += 1
+    x = xarray.concat([model_utils.dataset_to_stacked(inputs),
+                       model_utils.dataset_to_stacked(forcings)], dim="channels")
+    data = x.data
+    if xarray._is_torch(data):
+      import torch
+      y = torch.tanh(data.to(torch.float32) @ torch.from_numpy(self.a).to(data.device))
+    else:
+      y = np.tanh(np.asarray(data, np.float32) @ self.a)
+    return model_utils.stacked_to_dataset(
+        xarray.Variable(("batch", "lat", "lon", "channels"), y), targets_template)
+
+
+def _example(steps=4, seed=0):
+  return synthetic.make_example(TASK, LAT, LON, num_target_steps=steps, seed=seed)
+
+
+def _toy():
+  i, t, f = _example(1)
+  c_in = (model_utils.dataset_to_stacked(i).sizes["channels"]
+          + model_utils.dataset_to_stacked(f).sizes["channels"])
+  c_out = model_utils.dataset_to_stacked(t).sizes["channels"]
+  return ToyStep(c_in, c_out)
+
+
+# ----------------------------------------------------------------------------- stacking
+def test_channel_order_matches_reference_convention():
+  """sorted variable names; (time, level) time-major inside a variable."""
+  inputs, template, forcings = _example(1)
+  stacked = model_utils.dataset_to_stacked(inputs)
+  assert stacked.dims == ("batch", "lat", "lon", "channels")
+  n_lev = len(TASK.pressure_levels)
+  start = 0
+  for name in sorted(inputs.keys()):
+    v = inputs[name]
+    n = int(np.prod([s for d, s in v.sizes.items() if d not in ("batch", "lat", "lon")]))
+    block = stacked.values[..., start:start + n]
+    if "level" in v.dims:
+      assert n == 2 * n_lev
+      for t in range(2):
+        for l in range(n_lev):
+          want = v.values[:, t, l]                      # (batch, lat, lon)
+          np.testing.assert_array_equal(block[..., t * n_lev + l], want)
+    elif v.dims == ("lat", "lon"):
+      np.testing.assert_array_equal(block[0, ..., 0], v.values)
+    elif v.dims == ("batch", "time"):
+      assert n == 2
+      np.testing.assert_array_equal(block[0, 3, 2, :], v.values[0])   # broadcast over the grid
+    else:
+      np.testing.assert_array_equal(np.moveaxis(block, -1, 1), v.values)
+    start += n
+  assert start == stacked.sizes["channels"]
+  # 5 surface + 6 atmos, 2 frames; 5 forcings x 2 frames; 2 statics
+  assert start == 2 * (5 + 6 * n_lev) + 2 * 5 + 2
+
+
+def test_stack_unstack_round_trip_and_errors():
+  _, template, _ = _example(1)
+  data = {k: np.random.default_rng(1).standard_normal(template[k].shape).astype(np.float32)
+          for k in template.keys()}
+  ds = xarray.Dataset({k: (template[k].dims, data[k]) for k in data}, coords=dict(template._coords))
+  stacked = model_utils.dataset_to_stacked(ds)
+  grid = model_utils.lat_lon_to_leading_axes(stacked)
+  assert grid.dims == ("lat", "lon", "batch", "channels")
+  back = model_utils.stacked_to_dataset(model_utils.restore_leading_axes(grid).variable, template)
+  for k in data:
+    assert back[k].dims == template[k].dims
+    np.testing.assert_array_equal(back[k].values, data[k])
+  with pytest.raises(ValueError, match="channels"):
+    model_utils.stacked_to_dataset(stacked.variable.isel(channels=slice(0, 5)), template)
+
+
+# ----------------------------------------------------------------------------- rollout
+def _manual_rollout(step, inputs, template, forcings):
+  """Independent restatement with raw numpy windows (what rollout.py must reproduce)."""
+  window = {k: inputs[k].values.copy() for k in inputs.keys()}
+  outs = []
+  for t in range(template.sizes["time"]):
+    cur = xarray.Dataset({k: (inputs[k].dims, window[k]) for k in window}, coords=dict(
+        lat=LAT, lon=LON, level=np.asarray(TASK.pressure_levels), time=inputs.coords["time"].values))
+    pred = step(cur, template.isel(time=slice(0, 1)), forcings.isel(time=slice(t, t + 1)))
+    outs.append({k: pred[k].values for k in pred.keys()})
+    for k in window:
+      if "time" not in inputs[k].dims:
+        continue
+      tax = inputs[k].dims.index("time")
+      new = pred[k].values if k in pred.keys() else forcings[k].values.take([t], axis=forcings[k].dims.index("time"))
+      window[k] = np.concatenate([window[k], new], axis=tax).take([1, 2], axis=tax)
+  return {k: np.concatenate([o[k] for o in outs], axis=template[k].dims.index("time")) for k in outs[0]}
+
+
+def test_chunked_prediction_equals_manual_window_loop():
+  inputs, template, forcings = _example(4)
+  step = _toy()
+  fn = lambda rng, inputs, targets_template, forcings: step(inputs, targets_template, forcings)
+  got = rollout.chunked_prediction(fn, rng=0, inputs=inputs, targets_template=template,
+                                   forcings=forcings, num_steps_per_chunk=1)
+  want = _manual_rollout(_toy(), inputs, template, forcings)
+  assert step.calls == 4
+  for k in want:
+    np.testing.assert_allclose(got[k].values, want[k], rtol=0, atol=0)
+    assert got[k].dims == template[k].dims
+  np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)
+  np.testing.assert_array_equal(got.coords["datetime"].values, template.coords["datetime"].values)
+  # the caller's datasets are not mutated
+  assert "datetime" in inputs.coords and "datetime" in template.coords
+
+
+def test_autoregressive_predictor_equals_chunked_rollout():
+  inputs, template, forcings = _example(3)
+  a = autoregressive.Predictor(_toy())(inputs, template, forcings)
+  step = _toy()
+  b = rollout.chunked_prediction(lambda rng, **kw: step(**kw), None, inputs, template, forcings)
+  for k in template.keys():
+    np.testing.assert_array_equal(a[k].values, b[k].values)
+  # chunks of more than one step through the autoregressive wrapper
+  ar = autoregressive.Predictor(_toy())
+  c = rollout.chunked_prediction(lambda rng, **kw: ar(**kw), None, *_example(4)[:2],
+                                 forcings=_example(4)[2], num_steps_per_chunk=2)
+  d = rollout.chunked_prediction(lambda rng, **kw: _toy()(**kw), None, *_example(4)[:2],
+                                 forcings=_example(4)[2], num_steps_per_chunk=1)
+  for k in template.keys():
+    np.testing.assert_array_equal(c[k].values, d[k].values)
+
+
+def test_rollout_error_behaviour():
+  inputs, template, forcings = _example(3)
+  fn = lambda rng, **kw: _toy()(**kw)
+  with pytest.raises(ValueError, match="evenly divide"):
+    rollout.chunked_prediction(fn, None, inputs, template, forcings, num_steps_per_chunk=2)
+  bad = template.assign_coords(time=np.array([6, 12, 24]) * np.timedelta64(1, "h"))
+  bad_f = forcings.assign_coords(time=np.array([6, 12, 24]) * np.timedelta64(1, "h"))
+  with pytest.raises(ValueError, match="evenly spaced"):
+    rollout.chunked_prediction(fn, None, inputs, bad.drop_vars(["datetime"]), bad_f.drop_vars(["datetime"]))
+  with pytest.raises(ValueError, match="pmap_devices"):
+    next(rollout.chunked_prediction_generator(fn, None, inputs, template, 1, forcings, pmap_devices=[0]))
+  # an input with a time axis that is neither predicted nor forced cannot be rolled
+  extra = inputs.assign(mystery=inputs["2m_temperature"])
+  toy = ToyStep(2 * (5 + 18) + 10 + 2 + 2 + 5, 5 + 18)
+  with pytest.raises(ValueError, match="not predicted or forced"):
+    rollout.chunked_prediction(lambda rng, **kw: toy(**kw), None, extra, template, forcings)
+  with pytest.raises(ValueError, match="auto-regressive"):
+    autoregressive.Predictor(toy)(extra, template, forcings)
+
+
+def test_extend_targets_template():
+  _, template, _ = _example(1)
+  ext = rollout.extend_targets_template(template, 40)
+  assert ext.sizes["time"] == 40
+  np.testing.assert_array_equal(ext.coords["time"].values, (np.arange(40) + 1) * np.timedelta64(6, "h"))
+  assert ext["temperature"].shape == (1, 40, 3, len(LAT), len(LON))
+  assert ext["temperature"].data.strides[1] == 0          # nothing of the extended size is allocated
+  assert ext.coords["datetime"].values[0] == template.coords["datetime"].values[0, 0]
+
+
+def test_torch_backed_rollout_matches_numpy():
+  torch = pytest.importorskip("torch")
+  inputs, template, forcings = _example(3)
+  fn = lambda rng, **kw: _toy()(**kw)
+  want = rollout.chunked_prediction(fn, None, inputs, template, forcings)
+  put = lambda ds: synthetic.to_device(ds, "cpu")
+  chunks = list(rollout.chunked_prediction_generator(fn, None, inputs, template, 1, forcings,
+                                                     device_put_fn=put))
+  assert all(torch.is_tensor(c["temperature"].data) for c in chunks)
+  got = rollout.chunked_prediction(fn, None, inputs, template, forcings, device_put_fn=put)
+  for k in template.keys():
+    assert isinstance(got[k].data, np.ndarray)
+    np.testing.assert_allclose(got[k].values, want[k].values, rtol=1e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- normalisation
+def test_inputs_and_residuals_formula():
+  inputs, template, forcings = _example(1)
+  mean, std, dstd = synthetic.make_stats(TASK)
+  seen = {}
+
+  class Spy(ToyStep):
+    def __call__(self, inputs, targets_template, forcings, **kw):
+      seen["inputs"], seen["forcings"] = inputs, forcings
+      return super().__call__(inputs, targets_template, forcings)
+
+  t = _toy()
+  spy = Spy(t.a.shape[0], t.a.shape[1])
+  out = normalization.InputsAndResiduals(spy, std, mean, dstd)(inputs, template, forcings)
+  lev = lambda s, k: s[k].values.reshape((1, 1, -1, 1, 1)) if s[k].dims else s[k].values
+  for k in ("temperature", "2m_temperature", "land_sea_mask"):
+    want = (inputs[k].values - lev(mean, k)) / lev(std, k)
+    np.testing.assert_allclose(seen["inputs"][k].values, want, rtol=1e-6)
+  k = "toa_incident_solar_radiation"
+  np.testing.assert_allclose(seen["forcings"][k].values,
+                             (forcings[k].values - mean[k].values) / std[k].values, rtol=1e-6)
+  raw = spy.__class__.__mro__[1].__call__(spy, seen["inputs"], template, seen["forcings"])
+  for k in template.keys():          # every target is also an input -> residual branch
+    want = raw[k].values * lev(dstd, k) + inputs[k].values[:, -1:]
+    np.testing.assert_allclose(out[k].values, want, rtol=1e-6, atol=1e-6)
+    assert out[k].dims == template[k].dims
+  # a target that is not an input is un-normalised directly
+  task2 = dataclasses.replace(TASK, input_variables=tuple(
+      v for v in TASK.input_variables if v != "total_precipitation_6hr"))
+  i2, t2, f2 = synthetic.make_example(task2, LAT, LON)
+  toy2 = ToyStep(t.a.shape[0] - 2, t.a.shape[1])
+  out2 = normalization.InputsAndResiduals(toy2, std, mean, dstd)(i2, t2, f2)
+  raw2 = toy2(normalization.normalize(i2, std, mean), t2, normalization.normalize(f2, std, mean))
+  k = "total_precipitation_6hr"
+  np.testing.assert_allclose(out2[k].values, raw2[k].values * std[k].values + mean[k].values, rtol=1e-6)
+
+
+# ----------------------------------------------------------------------------- checkpoint
+@dataclasses.dataclass
+class _Sub:
+  a: int
+  b: str
+
+
+@dataclasses.dataclass
+class _Config:
+  bt: bool
+  bf: bool
+  i: int
+  f: float
+  o1: Optional[int]
+  o2: Optional[int]
+  li: list[int]
+  ls: list[str]
+  ldc: list[_Sub]
+  tf: tuple[int, ...]
+  t: tuple[str, int, _Sub]
+  dis: dict[int, str]
+  dsdis: dict[str, dict[int, str]]
+  dc: _Sub
+  dco: Optional[_Sub]
+  ddc: dict[str, _Sub]
+
+
+@dataclasses.dataclass
+class _Ckpt:
+  params: dict[str, Any]
+  config: _Config
+
+
+def test_checkpoint_round_trip_like_reference_test():
+  """Same shape of tree as checkpoint_test.py:65-120."""
+  ck = _Ckpt(
+      params={"layer1": {"w": np.arange(10).reshape(2, 5), "b": np.array([2, 6])},
+              "blah": np.array([3, 9])},
+      config=_Config(bt=True, bf=False, i=42, f=3.14, o1=1, o2=None,
+                     li=[12, 9, 7, 15, 16, 14, 1, 6, 11, 4, 10, 5, 13, 3, 8, 2],
+                     ls=list("qhjfdxtpzgemryoikwvblcaus"), ldc=[_Sub(1, "hello"), _Sub(2, "world")],
+                     tf=(1, 4, 2, 10, 5, 9, 13, 16, 15, 8, 12, 7, 11, 14, 3, 6),
+                     t=("foo", 42, _Sub(1, "bar")), dis={1: "a", 2: "b", 3: "c"},
+                     dsdis={"a": {1: "hello", 2: "world"}, "b": {1: "world"}},
+                     dc=_Sub(1, "hello"), dco=None, ddc={"a": _Sub(1, "hello"), "b": _Sub(2, "world")}))
+  buf = io.BytesIO()
+  checkpoint.dump(buf, ck)
+  buf.seek(0)
+  assert "params:layer1:w" in np.load(io.BytesIO(buf.getvalue())).files    # the reference's key layout
+  ck2 = checkpoint.load(buf, _Ckpt)
+  np.testing.assert_array_equal(ck.params["layer1"]["w"], ck2.params["layer1"]["w"])
+  np.testing.assert_array_equal(ck.params["blah"], ck2.params["blah"])
+  assert ck.config == ck2.config
+
+
+def test_graphcast_checkpoint_round_trip():
+  from graphcast_amd import params as gparams
+  p = gparams.random_params(10, 7, 512, 1)
+  ck = gc.CheckPoint(params=p, model_config=gc.ModelConfig(1.0, 5, 512, 16, 1, 0.6),
+                     task_config=gc.TASK_13, description="synthetic", license="none")
+  buf = io.BytesIO()
+  checkpoint.dump(buf, ck)
+  buf.seek(0)
+  ck2 = checkpoint.load(buf, gc.CheckPoint)
+  assert ck2.model_config == ck.model_config and ck2.task_config == ck.task_config
+  assert set(ck2.params) == set(p)
+  for k in p:
+    for leaf in p[k]:
+      np.testing.assert_array_equal(ck2.params[k][leaf], p[k][leaf])
+  gparams.check_params(ck2.params, 10, 7, 512, 1)
+
+
+# ----------------------------------------------------------------------------- ensemble sharding
+def test_member_ownership_partitions_the_ensemble():
+  for members, world in ((8, 8), (8, 2), (5, 4), (3, 8), (1, 1)):
+    owned = [ensemble.members_of_rank(members, r, world) for r in range(world)]
+    assert sorted(m for o in owned for m in o) == list(range(members))
+    assert max(map(len, owned)) - min(map(len, owned)) <= 1
+    for r, o in enumerate(owned):
+      assert all(ensemble.owner_of_member(m, world) == r for m in o)
+  with pytest.raises(ValueError):
+    ensemble.members_of_rank(4, 2, 2)
+
+
+def test_multiple_runs_rank_sharding_covers_all_members_once():
+  inputs, template, forcings = _example(2)
+  members = 3
+  # members differ in their inputs ("sample" axis on inputs)
+  stack = lambda ds: xarray.Dataset(
+      {k: ((("sample",) + ds[k].dims), np.stack([ds[k].values + 0.1 * m for m in range(members)]))
+       if "time" in ds[k].dims else (ds[k].dims, ds[k].values) for k in ds.keys()},
+      coords=dict(ds._coords))
+  s_inputs = stack(inputs)
+  fn = lambda rng, **kw: _toy()(**kw)
+  full = list(rollout.chunked_prediction_generator_multiple_runs(
+      fn, [0, 1, 2], s_inputs, template, forcings, num_samples=None, num_steps_per_chunk=1))
+  assert [int(c.coords["sample"].values) for c in full] == [0, 0, 1, 1, 2, 2]
+  by_rank = [list(rollout.chunked_prediction_generator_multiple_runs(
+      fn, [0, 1, 2], s_inputs, template, forcings, num_samples=3, num_steps_per_chunk=1,
+      rank=r, world_size=2)) for r in range(2)]
+  assert [int(c.coords["sample"].values) for c in by_rank[0]] == [0, 0, 2, 2]
+  assert [int(c.coords["sample"].values) for c in by_rank[1]] == [1, 1]
+  merged = {(int(c.coords["sample"].values), i % 2): c for chunks in by_rank for i, c in enumerate(chunks)}
+  for i, c in enumerate(full):
+    other = merged[(int(c.coords["sample"].values), i % 2)]
+    np.testing.assert_array_equal(c["temperature"].values, other["temperature"].values)
+  # member 1 really differs from member 0
+  assert not np.array_equal(full[0]["temperature"].values, full[2]["temperature"].values)
+  with pytest.raises(ValueError, match="Inconsistent number of rngs"):
+    next(rollout.chunked_prediction_generator_multiple_runs(
+        fn, [0], s_inputs, template, forcings, num_samples=3, num_steps_per_chunk=1))
+
+
+def test_with_sample_dim_broadcasts():
+  inputs, template, forcings = _example(1)
+  seen = {}
+
+  class Probe(predictor_base.Predictor):
+    def __call__(self, inputs, targets_template, forcings, **kw):
+      seen["dims"] = inputs["temperature"].dims
+      seen["shape"] = inputs["temperature"].shape
+      return targets_template
+
+  ensemble.WithSampleDim(Probe(), 4)(inputs, template, forcings)
+  assert seen["dims"][0] == "sample" and seen["shape"][0] == 4
