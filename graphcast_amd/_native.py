@@ -14,6 +14,8 @@ _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
 OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
+PREC_F32, PREC_F16X3 = 0, 1
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 LATENT = 512
 TILE_ROWS = 64
 K_CHUNK = 32
@@ -24,7 +26,8 @@ _fp = ctypes.c_void_p     # device pointers travel as integers
 class RowMlpDesc(ctypes.Structure):
   """struct gc_rowmlp_desc (include/gcast.h) -- field order must match exactly."""
   _fields_ = [
-      ("mode", ctypes.c_int), ("n_rows", ctypes.c_int),
+      ("mode", ctypes.c_int), ("prec", ctypes.c_int), ("n_rows", ctypes.c_int),
+      ("reserved0", ctypes.c_int),
       ("a0", _fp), ("lda0", ctypes.c_int), ("k0", ctypes.c_int),
       ("a1", _fp), ("lda1", ctypes.c_int), ("k1", ctypes.c_int),
       ("w1p", _fp),

@@ -24,6 +24,9 @@
 #include "gcast.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 #ifndef GC_STAGE_GLDS
 #define GC_STAGE_GLDS 1
@@ -166,6 +169,120 @@ __device__ __forceinline__ void mma_chunk(f4 (&acc)[kNB], const float* wb, f4 b0
   mma_group<NBLK, NP, NP_NEXT, 0>(acc, base0, base1, a0, a1, b0, b1, next_src, next_dst, wave, lane);
 }
 
+// ---------------------------------------------------------------------------------------
+// GC_PREC_F16X3: fp32-grade GEMMs on the f16 matrix cores.  x = x_hi + x_lo with
+// x_hi = fp16(x), x_lo = fp16(x - x_hi) (22 mantissa bits; the subtraction is exact in fp32),
+// x.w ~= x_hi.w_hi + x_lo.w_hi + x_hi.w_lo, three v_mfma_f32_16x16x32_f16 accumulating in
+// fp32.  Same transposed, register-chained formulation as the fp32 path:
+//   A operand = weights: lane l = 16 g + n supplies W[kmap(g, j)][16 nb + n], j < 8 (one
+//               ds_read_b128 of the pre-split hi (or lo) image, conflict-free: 64 lanes x 16 B
+//               contiguous)
+//   B operand = rows:    lane l = 16 g + i supplies X[row i][kmap(g, j)], split in registers
+//   C/D       = lane l, reg r: out[row i][16 nb + 4 g + r]   (identical to the fp32 path)
+// so two adjacent accumulator blocks (2c, 2c+1) are, after the split, the B operand of K step
+// c of the next layer ("chained" kmap, see gcast.h).
+__device__ __forceinline__ f4 mfma32h(u4 a, u4 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b),
+                                                c, 0, 0, 0);
+}
+
+constexpr float kHalfMax = 65504.0f;
+
+// (a, b) -> packed halves hi, lo.  Saturating: beyond +-65504 hi clamps and lo carries the
+// excess (exact up to 1.3e5), instead of producing inf.
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const float ca = __builtin_amdgcn_fmed3f(a, -kHalfMax, kHalfMax);
+  const float cb = __builtin_amdgcn_fmed3f(b, -kHalfMax, kHalfMax);
+  const h2 h = {static_cast<_Float16>(ca), static_cast<_Float16>(cb)};
+  const float ra = __builtin_amdgcn_fmed3f(a - static_cast<float>(h.x), -kHalfMax, kHalfMax);
+  const float rb = __builtin_amdgcn_fmed3f(b - static_cast<float>(h.y), -kHalfMax, kHalfMax);
+  const h2 l = {static_cast<_Float16>(ra), static_cast<_Float16>(rb)};
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+__device__ __forceinline__ void split8(f4 a, f4 b, u4& hi, u4& lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split2(a.x, a.y, h0, l0);
+  split2(a.z, a.w, h1, l1);
+  split2(b.x, b.y, h2, l2);
+  split2(b.z, b.w, h3, l3);
+  hi = u4{h0, h1, h2, h3};
+  lo = u4{l0, l1, l2, l3};
+}
+
+// Group T of a chunk = 4 n-blocks = 12 MFMAs (192 issue cycles).  Issue order, pinned by
+// scheduling fences as in the fp32 path:
+//   1. this group's share of the NEXT chunk's LDS-DMA,
+//   2. the four hi.hi MFMAs (their fragments were requested one group ago),
+//   3. the 8 ds_read_b128 of group T+1's fragments,
+//   4. the lo.hi and hi.lo MFMAs, which cover the latency of 3.
+// Every accumulator sees its three dependent MFMAs four issue slots apart.
+template <int NBLK, int PIECES, int T>
+__device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const u4 (&ah)[4],
+                                            const u4 (&al)[4], u4 bh, u4 bl,
+                                            const float* __restrict__ next_src, float* next_dst,
+                                            int wave, int lane) {
+  constexpr int kGroups = (NBLK + 3) / 4;
+  constexpr int n0 = 4 * T;
+  constexpr int cnt = NBLK - n0 < 4 ? NBLK - n0 : 4;
+  constexpr int kPpg = (PIECES + kGroups - 1) / kGroups;
+  constexpr bool more = T + 1 < kGroups;
+  constexpr int cnt2 = more ? (NBLK - n0 - 4 < 4 ? NBLK - n0 - 4 : 4) : 0;
+#pragma unroll
+  for (int p = 0; p < kPpg; ++p) {
+    if (T * kPpg + p < PIECES) stage_piece(next_src, next_dst, T * kPpg + p, wave, lane);
+  }
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+  for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  u4 nh[4], nl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < cnt2) {
+      nh[q] = wb[(n0 + 4 + q) * 128];
+      nl[q] = wb[(n0 + 4 + q) * 128 + 64];
+    } else {
+      nh[q] = ah[q];
+      nl[q] = al[q];
+    }
+  }
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+  for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bl, acc[n0 + q]);
+#pragma unroll
+  for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(al[q], bh, acc[n0 + q]);
+#if GC_SCHED_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  if constexpr (more) {
+    mma16_group<NBLK, PIECES, T + 1>(acc, wb, nh, nl, bh, bl, next_src, next_dst, wave, lane);
+  }
+}
+
+// acc[nb] += W-chunk(32 k) . B for nb < NBLK; `wbuf` = the chunk's LDS image, (bh, bl) the split
+// B operand; PIECES 1 KiB-per-wave pieces of the next chunk are DMA'd to next_dst meanwhile.
+template <int NBLK, int PIECES>
+__device__ __forceinline__ void mma16_chunk(f4 (&acc)[kNB], const float* wbuf, u4 bh, u4 bl,
+                                            const float* __restrict__ next_src, float* next_dst,
+                                            int wave, int lane) {
+  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
+  u4 ah[4], al[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ah[q] = wb[(q < NBLK ? q : 0) * 128];
+    al[q] = wb[(q < NBLK ? q : 0) * 128 + 64];
+  }
+  mma16_group<NBLK, PIECES, 0>(acc, wb, ah, al, bh, bl, next_src, next_dst, wave, lane);
+}
+
 __device__ __forceinline__ float swish1(float x) {
   // x * sigmoid(x); __expf/fast reciprocal are ~1-2 ulp, far inside the 1e-4 budget.
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
@@ -178,35 +295,10 @@ __device__ __forceinline__ float group_sum4(float v) {
   return v;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool kLinear = MODE == GC_MODE_LINEAR;
-  constexpr int NP2 = MODE == GC_MODE_MLP_OUT ? 256 : 512;
-  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
+// ---- pieces shared by the two arithmetic modes ----------------------------------------
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int i = lane & 15;          // row within the wave's 16 (B/C column), n within block (A row)
-  const int g = lane >> 4;          // k sub-group (A/B), n sub-group (C)
-  const int tile = blockIdx.x;
-  const int row = tile * GC_TILE_ROWS + wave * 16 + i;
-  const int rowc = row < d.n_rows ? row : d.n_rows - 1;
-  const int col0 = 4 * g;           // this lane's first column inside a 16-wide n block
-
-  const int n1 = (d.k0 + d.k1) >> 5;
-  const int n1a = d.k0 >> 5;
-  int q = 0;                        // position in the weight-chunk stream -> LDS buffer parity
-
-  if (n1 > 0) {
-    stage_chunk<512>(d.w1p, smem, tid);
-  } else if (!kLinear) {
-    stage_chunk<NP2>(d.w2p, smem, tid);
-  }
-
-  // ---- layer-1 accumulators start from the addends -------------------------------
-  f4 acc[kNB];
+// Layer-1 accumulators start from the addends: b1 + d[row] + g0[idx0[row]] + g1[idx1[row]].
+__device__ __forceinline__ void init_addends(f4 (&acc)[kNB], const gc_rowmlp_desc& d, int rowc, int col0) {
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
   if (d.b1) {
@@ -232,55 +324,17 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(p + nb * 16);
   }
+}
 
-  // ---- layer 1: acc += A . W1, A rows streamed from global as B operands ---------
-  if (n1 > 0) {
-    const float* arow0 = d.a0 + (size_t)rowc * d.lda0 + col0;
-    const float* arow1 = d.k1 ? d.a1 + (size_t)rowc * d.lda1 + col0 : arow0;
-    f4 bc0, bc1, bn0, bn1;
-    {
-      const float* p = n1a > 0 ? arow0 : arow1;
-      bc0 = *reinterpret_cast<const f4*>(p);
-      bc1 = *reinterpret_cast<const f4*>(p + 16);
-    }
-    bn0 = bc0;
-    bn1 = bc1;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    for (int c = 0; c + 1 < n1; ++c) {
-      __syncthreads();   // chunk c landed in LDS; previous chunk's readers are done
-      {
-        const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
-        bn0 = *reinterpret_cast<const f4*>(p);
-        bn1 = *reinterpret_cast<const f4*>(p + 16);
-      }
-      mma_chunk<kNB, 512, 512>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g,
-                               d.w1p + (size_t)(c + 1) * kBufFloats,
-                               smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
-      bc0 = bn0;
-      bc1 = bn1;
-      ++q;
-    }
-    __syncthreads();     // last layer-1 chunk; the first layer-2 chunk streams in behind it
-    if (kLinear) {
-      mma_chunk<kNB, 512, 0>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g, nullptr, nullptr,
-                             wave_u, lane);
-    } else {
-      mma_chunk<kNB, 512, NP2>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g, d.w2p,
-                               smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
-    }
-    ++q;
-  }
-
-  if (kLinear) {
-    if (row < d.n_rows) {
-      float* o = d.out + (size_t)row * d.ldo + col0;
+__device__ __forceinline__ void store_linear(const f4 (&acc)[kNB], const gc_rowmlp_desc& d, int row, int col0) {
+  if (row < d.n_rows) {
+    float* o = d.out + (size_t)row * d.ldo + col0;
 #pragma unroll
-      for (int nb = 0; nb < kNB; ++nb) *reinterpret_cast<f4*>(o + nb * 16) = acc[nb];
-    }
-    return;
+    for (int nb = 0; nb < kNB; ++nb) *reinterpret_cast<f4*>(o + nb * 16) = acc[nb];
   }
+}
 
-  // ---- swish in place: acc becomes the hidden layer, already in B-operand layout -
+__device__ __forceinline__ void swish_all(f4 (&acc)[kNB]) {
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) {
     acc[nb].x = swish1(acc[nb].x);
@@ -288,28 +342,13 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
     acc[nb].z = swish1(acc[nb].z);
     acc[nb].w = swish1(acc[nb].w);
   }
+}
 
-  // ---- layer 2: out = hidden . W2 + b2 (fully unrolled: hidden regs are indexed by chunk)
-  f4 o2[kNB];
-#pragma unroll
-  for (int nb = 0; nb < NB2; ++nb) o2[nb] = *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
-  {
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-    for (int cc = 0; cc < kD / 32; ++cc) {
-      __syncthreads();
-      if (cc + 1 < kD / 32) {
-        mma_chunk<NB2, NP2, NP2>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g,
-                                 d.w2p + (size_t)(cc + 1) * (8 * NP2 * 4),
-                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
-      } else {
-        mma_chunk<NB2, NP2, 0>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g,
-                               nullptr, nullptr, wave_u, lane);
-      }
-      ++q;
-    }
-  }
-
+// Everything after layer 2: decoder store, or LayerNorm -> [+ residual] store -> segment-sum.
+template <int MODE>
+__device__ __forceinline__ void finish_rows(f4 (&o2)[kNB], const gc_rowmlp_desc& d, float* smem, int tile,
+                                            int row, int wave, int i, int col0, int tid) {
+  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
   if (MODE == GC_MODE_MLP_OUT) {
     if (row < d.n_rows) {
       float* o = d.out + (size_t)row * d.ldo;
@@ -405,6 +444,213 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
   }
 }
 
+// ---- GC_PREC_F32 ------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool kLinear = MODE == GC_MODE_LINEAR;
+  constexpr int NP2 = MODE == GC_MODE_MLP_OUT ? 256 : 512;
+  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i = lane & 15;          // row within the wave's 16 (B/C column), n within block (A row)
+  const int g = lane >> 4;          // k sub-group (A/B), n sub-group (C)
+  const int tile = blockIdx.x;
+  const int row = tile * GC_TILE_ROWS + wave * 16 + i;
+  const int rowc = row < d.n_rows ? row : d.n_rows - 1;
+  const int col0 = 4 * g;           // this lane's first column inside a 16-wide n block
+  const float* w1p = static_cast<const float*>(d.w1p);
+  const float* w2p = static_cast<const float*>(d.w2p);
+
+  const int n1 = (d.k0 + d.k1) >> 5;
+  const int n1a = d.k0 >> 5;
+  int q = 0;                        // position in the weight-chunk stream -> LDS buffer parity
+
+  if (n1 > 0) {
+    stage_chunk<512>(w1p, smem, tid);
+  } else if (!kLinear) {
+    stage_chunk<NP2>(w2p, smem, tid);
+  }
+
+  f4 acc[kNB];
+  init_addends(acc, d, rowc, col0);
+
+  // ---- layer 1: acc += A . W1, A rows streamed from global as B operands ---------
+  if (n1 > 0) {
+    const float* arow0 = d.a0 + (size_t)rowc * d.lda0 + col0;
+    const float* arow1 = d.k1 ? d.a1 + (size_t)rowc * d.lda1 + col0 : arow0;
+    f4 bc0, bc1, bn0, bn1;
+    {
+      const float* p = n1a > 0 ? arow0 : arow1;
+      bc0 = *reinterpret_cast<const f4*>(p);
+      bc1 = *reinterpret_cast<const f4*>(p + 16);
+    }
+    bn0 = bc0;
+    bn1 = bc1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int c = 0; c + 1 < n1; ++c) {
+      __syncthreads();   // chunk c landed in LDS; previous chunk's readers are done
+      {
+        const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
+        bn0 = *reinterpret_cast<const f4*>(p);
+        bn1 = *reinterpret_cast<const f4*>(p + 16);
+      }
+      mma_chunk<kNB, 512, 512>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g,
+                               w1p + (size_t)(c + 1) * kBufFloats,
+                               smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+      bc0 = bn0;
+      bc1 = bn1;
+      ++q;
+    }
+    __syncthreads();     // last layer-1 chunk; the first layer-2 chunk streams in behind it
+    if (kLinear) {
+      mma_chunk<kNB, 512, 0>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g, nullptr, nullptr,
+                             wave_u, lane);
+    } else {
+      mma_chunk<kNB, 512, NP2>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g, w2p,
+                               smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+    }
+    ++q;
+  }
+
+  if (kLinear) {
+    store_linear(acc, d, row, col0);
+    return;
+  }
+
+  // ---- swish in place: acc becomes the hidden layer, already in B-operand layout -
+  swish_all(acc);
+
+  // ---- layer 2: out = hidden . W2 + b2 (fully unrolled: hidden regs are indexed by chunk)
+  f4 o2[kNB];
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb) o2[nb] = *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
+  {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int cc = 0; cc < kD / 32; ++cc) {
+      __syncthreads();
+      if (cc + 1 < kD / 32) {
+        mma_chunk<NB2, NP2, NP2>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g,
+                                 w2p + (size_t)(cc + 1) * (8 * NP2 * 4),
+                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+      } else {
+        mma_chunk<NB2, NP2, 0>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g,
+                               nullptr, nullptr, wave_u, lane);
+      }
+      ++q;
+    }
+  }
+  finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
+}
+
+// ---- GC_PREC_F16X3 ----------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool kLinear = MODE == GC_MODE_LINEAR;
+  constexpr int NP2 = MODE == GC_MODE_MLP_OUT ? 256 : 512;
+  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
+  constexpr int kPieces1 = 512 / 32;       // 1 KiB-per-wave DMA pieces of a layer-1 chunk
+  constexpr int kPieces2 = NP2 / 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i = lane & 15;
+  const int g = lane >> 4;
+  const int tile = blockIdx.x;
+  const int row = tile * GC_TILE_ROWS + wave * 16 + i;
+  const int rowc = row < d.n_rows ? row : d.n_rows - 1;
+  const int col0 = 4 * g;
+  const float* w1p = static_cast<const float*>(d.w1p);   // opaque 64 KiB chunks
+  const float* w2p = static_cast<const float*>(d.w2p);
+
+  const int n1 = (d.k0 + d.k1) >> 5;
+  const int n1a = d.k0 >> 5;
+  int q = 0;
+
+  if (n1 > 0) {
+    stage_chunk<512>(w1p, smem, tid);
+  } else if (!kLinear) {
+    stage_chunk<NP2>(w2p, smem, tid);
+  }
+
+  f4 acc[kNB];
+  init_addends(acc, d, rowc, col0);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  // ---- layer 1: the lane's 8 consecutive k of its row per chunk, split in registers ----
+  if (n1 > 0) {
+    const float* arow0 = d.a0 + (size_t)rowc * d.lda0 + 8 * g;
+    const float* arow1 = d.k1 ? d.a1 + (size_t)rowc * d.lda1 + 8 * g : arow0;
+    f4 xc0, xc1, xn0, xn1;
+    {
+      const float* p = n1a > 0 ? arow0 : arow1;
+      xc0 = *reinterpret_cast<const f4*>(p);
+      xc1 = *reinterpret_cast<const f4*>(p + 4);
+    }
+    xn0 = xc0;
+    xn1 = xc1;
+    u4 bh, bl;
+    for (int c = 0; c + 1 < n1; ++c) {
+      __syncthreads();
+      {
+        const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
+        xn0 = *reinterpret_cast<const f4*>(p);
+        xn1 = *reinterpret_cast<const f4*>(p + 4);
+      }
+      split8(xc0, xc1, bh, bl);
+      mma16_chunk<kNB, kPieces1>(acc, smem + (q & 1) * kBufFloats, bh, bl,
+                                 w1p + (size_t)(c + 1) * kBufFloats,
+                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+      xc0 = xn0;
+      xc1 = xn1;
+      ++q;
+    }
+    __syncthreads();
+    split8(xc0, xc1, bh, bl);
+    if (kLinear) {
+      mma16_chunk<kNB, 0>(acc, smem + (q & 1) * kBufFloats, bh, bl, nullptr, nullptr, wave_u, lane);
+    } else {
+      mma16_chunk<kNB, kPieces2>(acc, smem + (q & 1) * kBufFloats, bh, bl, w2p,
+                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+    }
+    ++q;
+  }
+
+  if (kLinear) {
+    store_linear(acc, d, row, col0);
+    return;
+  }
+
+  // ---- swish, then split the hidden layer once: blocks (2c, 2c+1) -> B operand of K step c
+  swish_all(acc);
+  u4 hh[kD / 32], hl[kD / 32];
+#pragma unroll
+  for (int cc = 0; cc < kD / 32; ++cc) split8(acc[2 * cc], acc[2 * cc + 1], hh[cc], hl[cc]);
+
+  f4 o2[kNB];
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb) o2[nb] = *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
+#pragma unroll
+  for (int cc = 0; cc < kD / 32; ++cc) {
+    __syncthreads();
+    if (cc + 1 < kD / 32) {
+      mma16_chunk<NB2, kPieces2>(o2, smem + (q & 1) * kBufFloats, hh[cc], hl[cc],
+                                 w2p + (size_t)(cc + 1) * (8 * NP2 * 4),
+                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+    } else {
+      mma16_chunk<NB2, 0>(o2, smem + (q & 1) * kBufFloats, hh[cc], hl[cc], nullptr, nullptr,
+                          wave_u, lane);
+    }
+    ++q;
+  }
+  finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
+}
+
 __global__ void seg_fixup_kernel(int n, const int* __restrict__ recv, const int* __restrict__ t0,
                                  const int* __restrict__ t1, const float* __restrict__ partial,
                                  float* __restrict__ agg) {
@@ -454,22 +700,28 @@ int check_launch(const char* what) {
   return 0;
 }
 
-bool g_attr_set[3] = {false, false, false};
+bool g_attr_set[2][3] = {{false, false, false}, {false, false, false}};
 
 template <int MODE>
 int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = kLdsFloats * sizeof(float);
-  if (!g_attr_set[MODE]) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp_kernel<MODE>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool split = d.prec == GC_PREC_F16X3;
+  if (!g_attr_set[split][MODE]) {
+    const void* fn = split ? reinterpret_cast<const void*>(&rowmlp16_kernel<MODE>)
+                           : reinterpret_cast<const void*>(&rowmlp_kernel<MODE>);
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
       return GC_ELAUNCH;
     }
-    g_attr_set[MODE] = true;
+    g_attr_set[split][MODE] = true;
   }
   const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
-  hipLaunchKernelGGL(rowmlp_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
+  if (split) {
+    hipLaunchKernelGGL(rowmlp16_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
+  } else {
+    hipLaunchKernelGGL(rowmlp_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
+  }
   return check_launch("rowmlp_kernel");
 }
 
@@ -484,6 +736,8 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   const gc_rowmlp_desc& d = *dp;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
+  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3) return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
+  if (d.reserved0 != 0) return fail(GC_EINVAL, "gc_rowmlp: reserved0 must be 0");
   if ((d.k0 | d.k1) & 31 || d.k0 < 0 || d.k1 < 0) return fail(GC_EINVAL, "gc_rowmlp: k0/k1 must be multiples of 32");
   if (d.k0 == 0 && d.k1 != 0) return fail(GC_EINVAL, "gc_rowmlp: k1 without k0");
   if (d.k0 + d.k1 > 0 && (!d.a0 || !d.w1p)) return fail(GC_EINVAL, "gc_rowmlp: layer-1 GEMM needs a0 and w1p");
@@ -610,9 +864,9 @@ const char* gc_last_error(void) { return g_err; }
 
 const char* gc_build_info(void) {
 #if GC_STAGE_GLDS
-  return "gfx950;stage=glds;tile=64x512;mfma=f32_16x16x4";
+  return "gfx950;stage=glds;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32";
 #else
-  return "gfx950;stage=regs;tile=64x512;mfma=f32_16x16x4";
+  return "gfx950;stage=regs;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32";
 #endif
 }
 

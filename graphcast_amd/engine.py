@@ -18,6 +18,7 @@ haiku parameter tree, and turns them into
 All arithmetic happens in libgcast_hip.so; torch only owns the memory.
 """
 import ctypes
+import os
 from typing import Dict, Mapping, Optional
 
 import numpy as np
@@ -28,6 +29,11 @@ from graphcast_amd import packing
 
 D = packing.LATENT
 
+# Arithmetic of the GEMMs (include/gcast.h `gc_precision`): "f16x3" = fp32 operands split into
+# two halves in registers, three f16 MFMAs per product, fp32 accumulation (fp32-grade results,
+# ~5x the fp32-MFMA rate); "f32" = exact fp32 MFMA.  Overridable with GCAST_PRECISION.
+DEFAULT_PRECISION = "f16x3"
+
 # stage tags reported by gc_time_program / used by bench.py
 TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, enc_node_grid=5,
             proc_pre=6, proc_edge=7, proc_node=8, dec_pre=9, dec_edge=10, dec_node=11,
@@ -37,7 +43,7 @@ TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, en
 class _Mlp:
   """Packed device copy of one `<stem>_mlp` (+ `<stem>_layer_norm`)."""
 
-  def __init__(self, params, stem, dev, split=None, np2=D):
+  def __init__(self, params, stem, dev, split=None, np2=D, prec=nat.PREC_F32):
     w1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["w"], dtype=np.float32)
     b1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["b"], dtype=np.float32)
     w2 = np.asarray(params[f"{stem}_mlp/~/linear_1"]["w"], dtype=np.float32)
@@ -47,17 +53,26 @@ class _Mlp:
     if w1.shape[1] != D or w2.shape[0] != D:
       raise NotImplementedError(f"latent/hidden size must be {D}, got {w1.shape}, {w2.shape}")
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if prec == nat.PREC_F16X3:
+      # (hi, lo) fp16 images; layer 1 reads rows from memory (natural K order), layer 2 is fed by
+      # layer 1's accumulator registers (chained K order) -- include/gcast.h.  Stored as int16
+      # bit patterns: the kernels only ever see the raw chunk image.
+      pack1 = lambda w: packing.pack_weight_split(w).view(np.int16)
+      pack2 = lambda w, np_cols: packing.pack_weight_split(w, np_cols=np_cols, chained=True).view(np.int16)
+    else:
+      pack1 = packing.pack_weight
+      pack2 = lambda w, np_cols: packing.pack_weight(w, np_cols=np_cols)
     self.k_in = w1.shape[0]
     self.n_out = w2.shape[1]
     # W1 either whole, or split into named row blocks of 512 (concat order)
     if split is None:
-      self.w1 = up(packing.pack_weight(w1))
+      self.w1 = up(pack1(w1))
       self.k1p = packing.round_up(w1.shape[0], packing.K_CHUNK)
     else:
       assert w1.shape[0] == D * len(split), (stem, w1.shape, split)
-      self.w1 = {name: up(packing.pack_weight(w1[j * D:(j + 1) * D])) for j, name in enumerate(split)}
+      self.w1 = {name: up(pack1(w1[j * D:(j + 1) * D])) for j, name in enumerate(split)}
     self.b1 = up(b1)
-    self.w2 = up(packing.pack_weight(w2, np_cols=np2))
+    self.w2 = up(pack2(w2, np2))
     self.b2 = up(packing.pad_vector(b2, np2))
     self.scale = self.offset = None
     if f"{stem}_layer_norm" in params:
@@ -83,9 +98,14 @@ class StepEngine:
   """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
 
   def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
-               device="cuda:0"):
+               device="cuda:0", precision: Optional[str] = None):
     self.dev = torch.device(device)
     self.lib = nat.lib()
+    precision = precision or os.environ.get("GCAST_PRECISION", DEFAULT_PRECISION)
+    if precision not in nat.PRECISIONS:
+      raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
+    self.precision = precision
+    self.prec = nat.PRECISIONS[precision]
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     self.c_in, self.c_out, self.num_steps = c_in, c_out, num_steps
     self.n_struct = graphs["grid_node_feat"].shape[1]
@@ -111,13 +131,12 @@ class StepEngine:
   def _stream_ptr(self):
     return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-  @staticmethod
-  def _desc(mode, n_rows, *, a0=None, k0=0, lda0=None, a1=None, k1=0, lda1=None, w1p=None,
+  def _desc(self, mode, n_rows, *, a0=None, k0=0, lda0=None, a1=None, k1=0, lda1=None, w1p=None,
             d=None, g0=None, idx0=None, g1=None, idx1=None, b1=None, w2p=None, b2=None, n2=0,
             ln=None, res=None, out=None, ldo=None, out_ptr=None, edges: Optional[_Edges] = None,
             agg=None):
     ds = nat.RowMlpDesc()
-    ds.mode, ds.n_rows = mode, n_rows
+    ds.mode, ds.n_rows, ds.prec = mode, n_rows, self.prec
     ds.a0, ds.k0, ds.lda0 = nat.ptr(a0), k0, (lda0 if lda0 is not None else (a0.shape[1] if a0 is not None else 0))
     ds.a1, ds.k1, ds.lda1 = nat.ptr(a1), k1, (lda1 if lda1 is not None else (a1.shape[1] if a1 is not None else 0))
     ds.w1p = nat.ptr(w1p)
@@ -170,21 +189,21 @@ class StepEngine:
     M = "mesh_gnn/~_networks_builder/"
     X = "mesh2grid_gnn/~_networks_builder/"
     esr = ("e", "s", "r")
-    self.m_enc_grid = _Mlp(params, G + "encoder_nodes_grid_nodes", dev)
-    m_enc_mesh = _Mlp(params, G + "encoder_nodes_mesh_nodes", dev)
-    m_enc_e_g2m = _Mlp(params, G + "encoder_edges_grid2mesh", dev)
-    self.m_g2m_edge = _Mlp(params, G + "processor_edges_0_grid2mesh", dev, split=esr)
-    self.m_g2m_mesh = _Mlp(params, G + "processor_nodes_0_mesh_nodes", dev, split=("h", "a"))
-    self.m_g2m_grid = _Mlp(params, G + "processor_nodes_0_grid_nodes", dev)
-    m_enc_e_mesh = _Mlp(params, M + "encoder_edges_mesh", dev)
-    self.m_proc_edge = [_Mlp(params, M + f"processor_edges_{i}_mesh", dev, split=esr)
+    self.m_enc_grid = _Mlp(params, G + "encoder_nodes_grid_nodes", dev, prec=self.prec)
+    m_enc_mesh = _Mlp(params, G + "encoder_nodes_mesh_nodes", dev, prec=self.prec)
+    m_enc_e_g2m = _Mlp(params, G + "encoder_edges_grid2mesh", dev, prec=self.prec)
+    self.m_g2m_edge = _Mlp(params, G + "processor_edges_0_grid2mesh", dev, split=esr, prec=self.prec)
+    self.m_g2m_mesh = _Mlp(params, G + "processor_nodes_0_mesh_nodes", dev, split=("h", "a"), prec=self.prec)
+    self.m_g2m_grid = _Mlp(params, G + "processor_nodes_0_grid_nodes", dev, prec=self.prec)
+    m_enc_e_mesh = _Mlp(params, M + "encoder_edges_mesh", dev, prec=self.prec)
+    self.m_proc_edge = [_Mlp(params, M + f"processor_edges_{i}_mesh", dev, split=esr, prec=self.prec)
                         for i in range(self.num_steps)]
-    self.m_proc_node = [_Mlp(params, M + f"processor_nodes_{i}_mesh_nodes", dev)
+    self.m_proc_node = [_Mlp(params, M + f"processor_nodes_{i}_mesh_nodes", dev, prec=self.prec)
                         for i in range(self.num_steps)]
-    m_enc_e_m2g = _Mlp(params, X + "encoder_edges_mesh2grid", dev)
-    self.m_m2g_edge = _Mlp(params, X + "processor_edges_0_mesh2grid", dev, split=esr)
-    self.m_m2g_grid = _Mlp(params, X + "processor_nodes_0_grid_nodes", dev)
-    self.m_out = _Mlp(params, X + "decoder_nodes_grid_nodes", dev, np2=256)
+    m_enc_e_m2g = _Mlp(params, X + "encoder_edges_mesh2grid", dev, prec=self.prec)
+    self.m_m2g_edge = _Mlp(params, X + "processor_edges_0_mesh2grid", dev, split=esr, prec=self.prec)
+    self.m_m2g_grid = _Mlp(params, X + "processor_nodes_0_grid_nodes", dev, prec=self.prec)
+    self.m_out = _Mlp(params, X + "decoder_nodes_grid_nodes", dev, np2=256, prec=self.prec)
     if self.m_out.n_out != self.c_out:
       raise ValueError(f"decoder produces {self.m_out.n_out} channels, task needs {self.c_out}")
     if self.m_enc_grid.k_in != self.c_in + self.n_struct:

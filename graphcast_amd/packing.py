@@ -40,6 +40,64 @@ def pack_weight(w, np_cols=LATENT):
   return np.ascontiguousarray(padded.reshape(kp // 4, 4, np_cols).transpose(0, 2, 1))
 
 
+def split_f16(x):
+  """x (float32) -> (hi, lo) float16 with hi = fp16(x), lo = fp16(x - hi): 22 mantissa bits.
+
+  Round-to-nearest both times; |x - (hi + lo)| <= max(2^-22 |x|, 2^-25) (the second term is
+  the fp16 subnormal spacing: tiny weights keep an ABSOLUTE error of 3e-8)."""
+  x = np.asarray(x, dtype=np.float32)
+  if np.abs(x).max(initial=0.0) > 65504.0:
+    raise ValueError("weight magnitude above the fp16 range (65504)")
+  hi = x.astype(np.float16)
+  lo = (x - hi.astype(np.float32)).astype(np.float16)
+  return hi, lo
+
+
+def _kmap(chained):
+  """k index inside a 32-chunk for (g, j): lane group g (4) supplies 8 k values j."""
+  g = np.arange(4)[:, None]
+  j = np.arange(8)[None, :]
+  if chained:
+    return np.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4))       # [4, 8]
+  return 8 * g + j
+
+
+def pack_weight_split(w, np_cols=LATENT, chained=False):
+  """[K, N] float32 -> uint16 [ceil32(K)/32, np_cols/16, 2, 64, 8]: the GC_PREC_F16X3 layout of
+  include/gcast.h.  Entry [c, nb, part, 16 g + n, j] = part(hi|lo) of w[32 c + kmap(g, j)][16 nb + n];
+  ``chained`` selects the K permutation of a layer fed by the previous layer's accumulator
+  registers (layer 2) instead of by rows read from memory (layer 1)."""
+  w = np.asarray(w, dtype=np.float32)
+  k, n = w.shape
+  if n > np_cols:
+    raise ValueError(f"weight has {n} columns, packed layout holds {np_cols}")
+  kp = round_up(k, K_CHUNK)
+  padded = np.zeros((kp, np_cols), dtype=np.float32)
+  padded[:k, :n] = w
+  hi, lo = split_f16(padded)
+  km = _kmap(chained)                                      # [4, 8]
+  out = np.empty((kp // K_CHUNK, np_cols // 16, 2, 4, 16, 8), dtype=np.float16)
+  for part, src in enumerate((hi, lo)):
+    blk = src.reshape(kp // K_CHUNK, K_CHUNK, np_cols // 16, 16)          # [c, k, nb, n]
+    gathered = blk[:, km, :, :]                                          # [c, g, j, nb, n]
+    out[:, :, part] = gathered.transpose(0, 3, 1, 4, 2)                  # [c, nb, g, n, j]
+  return np.ascontiguousarray(out.reshape(kp // K_CHUNK, np_cols // 16, 2, 64, 8)).view(np.uint16)
+
+
+def unpack_weight_split(wp, k, n, chained=False):
+  """Inverse of pack_weight_split -> (hi, lo) float32 [k, n] (tests)."""
+  wp = np.asarray(wp).view(np.float16)
+  chunks, nblk = wp.shape[0], wp.shape[1]
+  km = _kmap(chained)
+  parts = []
+  for part in range(2):
+    v = wp[:, :, part].reshape(chunks, nblk, 4, 16, 8).astype(np.float32)   # [c, nb, g, n, j]
+    full = np.zeros((chunks, K_CHUNK, nblk, 16), dtype=np.float32)
+    full[:, km, :, :] = v.transpose(0, 2, 4, 1, 3)                        # [c, g, j, nb, n]
+    parts.append(full.reshape(chunks * K_CHUNK, nblk * 16)[:k, :n])
+  return parts[0], parts[1]
+
+
 def unpack_weight(wp, k, n):
   """Inverse of pack_weight (tests)."""
   q, np_cols, _ = wp.shape

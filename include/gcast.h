@@ -13,7 +13,9 @@
  *     helper that synchronises by design);
  *   - return 0 on success, a negative GC_E* code otherwise; the message is in
  *     gc_last_error() (thread-local);
- *   - fp32 everywhere; latent size is fixed at 512 (GraphCast's
+ *   - fp32 tensors everywhere; the GEMMs run in one of two arithmetic modes
+ *     (`gc_rowmlp_desc.prec`, below) that both deliver fp32-grade results;
+ *     latent size is fixed at 512 (GraphCast's
  *     `latent_size`, weathernext1_graph/graphcast.py:123) and MLPs have exactly
  *     one hidden layer (`hidden_layers`, :124) -- other values are rejected
  *     loudly by the host code.
@@ -24,6 +26,17 @@
  * multiple of 32 and N to NP = 512 (or 256 for the decoder's last layer).
  * A 32-row K chunk is then one contiguous 8*NP*16-byte block that is DMA'd
  * linearly into LDS and read conflict-free as ds_read_b128 MFMA A-fragments.
+ *
+ * Split-f16 weight layout (prec == GC_PREC_F16X3): every weight is stored as the
+ * pair (hi, lo) of IEEE halves with hi = fp16(w), lo = fp16(w - hi) (22 mantissa
+ * bits).  A 32-row K chunk is [NP/16 n-blocks][2: hi, lo][64 lanes][8 halves]:
+ * lane l = 16*g + n of n-block nb holds W[kmap(g, j)][16*nb + n], j = 0..7 --
+ * exactly one v_mfma_f32_16x16x32_f16 A-fragment per 16 B.  kmap is
+ *   natural (layer 1, rows come from memory):  32*c + 8*g + j
+ *   chained (layer 2, rows are layer 1's accumulator registers):
+ *                                              32*c + 4*g + j        (j < 4)
+ *                                              32*c + 16 + 4*g + j-4 (j >= 4)
+ * Chunk size in bytes is the same as in the fp32 layout (NP * 128).
  */
 #ifndef GCAST_H_
 #define GCAST_H_
@@ -40,6 +53,17 @@ extern "C" {
 
 #define GC_EINVAL (-1)
 #define GC_ELAUNCH (-2)
+
+/* Arithmetic of the two GEMMs of a launch.  Inputs, outputs, accumulation, bias,
+ * LayerNorm, residual and segment-sum are fp32 in both modes.
+ *   GC_PREC_F32   v_mfma_f32_16x16x4_f32: exact fp32 products (157 TF peak).
+ *   GC_PREC_F16X3 each fp32 operand x is split in registers into two halves
+ *                 x = hi + lo (22 mantissa bits) and every product is formed as
+ *                 x_hi.w_hi + x_lo.w_hi + x_hi.w_lo with three
+ *                 v_mfma_f32_16x16x32_f16 accumulating in fp32 (dropped term
+ *                 ~2^-22): fp32-grade results at 1/3 of the 2.5 PF f16 MFMA
+ *                 peak.  |x| must stay below 1.3e5 (saturating split). */
+enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1 };
 
 /* What a fused row-MLP launch produces. */
 enum gc_rowmlp_mode {
@@ -69,18 +93,20 @@ enum gc_rowmlp_mode {
  */
 typedef struct gc_rowmlp_desc {
   int mode;                /* enum gc_rowmlp_mode */
+  int prec;                /* enum gc_precision: selects the layout w1p / w2p are packed in */
   int n_rows;              /* rows to process */
+  int reserved0;           /* keeps the pointers below 8-byte aligned; must be 0 */
   /* layer-1 GEMM sources (row-major, 16-byte aligned rows); k0,k1 multiples of 32, may be 0 */
   const float* a0; int lda0; int k0;
   const float* a1; int lda1; int k1;
-  const float* w1p;        /* packed [(k0+k1)/4][512][4]; NULL iff k0+k1 == 0 */
+  const void* w1p;         /* packed (k0+k1)/32 chunks of 64 KiB; NULL iff k0+k1 == 0 */
   /* addends to the pre-activation (each may be NULL) */
   const float* d;  int ldd;          /* direct rows d[r] */
   const float* g0; const int* idx0;  /* gathered rows g0[idx0[r]], row stride 512 */
   const float* g1; const int* idx1;
   const float* b1;         /* [512] */
   /* layer 2 (modes MLP_LN / MLP_OUT) */
-  const float* w2p;        /* packed [128][NP][4], NP = 512 (MLP_LN) or 256 (MLP_OUT) */
+  const void* w2p;         /* packed 16 chunks of NP*128 B, NP = 512 (MLP_LN) or 256 (MLP_OUT) */
   const float* b2;         /* [NP] (zero padded) */
   int n2;                  /* real output width: 512 (MLP_LN), <= 240 (MLP_OUT) */
   /* LayerNorm (mode MLP_LN; NULL scale => skip) */

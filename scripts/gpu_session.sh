@@ -30,13 +30,32 @@ echo "== bench" | tee -a "$OUT/summary.txt"
 timeout 1500 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "$OUT/summary.txt"; tail -5 "$OUT/bench.err" | tee -a "$OUT/summary.txt"
 
+if [ "${DO_F32:-0}" = "1" ]; then
+  echo "== bench (exact fp32 MFMA mode)" | tee -a "$OUT/summary.txt"
+  timeout 900 python bench.py --steps 2 --warmup 1 --precision f32 --no-cpu-baseline --no-cross-check > "$OUT/bench_f32.json" 2> "$OUT/bench_f32.err"
+  echo "bench f32 rc=$?" | tee -a "$OUT/summary.txt"; cut -c1-600 "$OUT/bench_f32.json" | tee -a "$OUT/summary.txt"
+fi
+
 if [ "${DO_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel trace" | tee -a "$OUT/summary.txt"
   (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- \
-      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --op-timing-iters 1 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
+      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
   echo "rocprof rc=$?" | tee -a "$OUT/summary.txt"
   find "$OUT/prof" -type f | head | tee -a "$OUT/summary.txt"
   for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do head -12 "$f" | cut -c1-220 | tee -a "$OUT/summary.txt"; done
   # keep only the small summaries (the raw trace can be large)
   find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
+fi
+
+if [ "${DO_PMC:-0}" = "1" ]; then
+  # HBM traffic counters: one pass per counter (FETCH_SIZE takes 3 of the 4 TCC slots), kernel-trace only
+  for C in FETCH_SIZE WRITE_SIZE; do
+    echo "== rocprofv3 --pmc $C" | tee -a "$OUT/summary.txt"
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OLDPWD/$OUT/pmc_$C" -o pmc -- \
+        python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/pmc_$C.json" 2> "$OLDPWD/$OUT/pmc_$C.err")
+    echo "pmc $C rc=$?" | tee -a "$OUT/summary.txt"
+    python scripts/pmc_summary.py "$OUT/pmc_$C" > "$OUT/pmc_$C.summary.csv" 2>> "$OUT/summary.txt"
+    head -8 "$OUT/pmc_$C.summary.csv" | cut -c1-200 | tee -a "$OUT/summary.txt"
+    find "$OUT/pmc_$C" -type f -size +20M -delete
+  done
 fi

@@ -108,3 +108,51 @@ def test_pack_edges_rejects_bad_input():
     packing.pack_edges(np.array([], dtype=int), np.array([], dtype=int), 3)
   with pytest.raises(ValueError):
     packing.pack_edges(np.array([0]), np.array([3]), 3)
+
+
+# ----------------------------------------------------------------------------- split-f16 layout
+def test_split_f16_keeps_22_bits_and_subnormal_floor():
+  rng = np.random.default_rng(0)
+  x = (rng.standard_normal(100000) * np.exp(rng.uniform(-12, 8, 100000))).astype(np.float32)
+  x = x[np.abs(x) < 6e4]
+  hi, lo = packing.split_f16(x)
+  err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - x)
+  assert (err <= np.maximum(2.0 ** -22 * np.abs(x), 2.0 ** -25)).all()
+  with pytest.raises(ValueError):
+    packing.split_f16(np.array([7e4], np.float32))
+
+
+@pytest.mark.parametrize("chained", [False, True])
+@pytest.mark.parametrize("k,n,np_cols", [(474, 512, 512), (512, 227, 256), (4, 512, 512)])
+def test_pack_weight_split_round_trip_and_lane_map(chained, k, n, np_cols):
+  rng = np.random.default_rng(k + n)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  wp = packing.pack_weight_split(w, np_cols=np_cols, chained=chained)
+  kp = packing.round_up(k, 32)
+  assert wp.shape == (kp // 32, np_cols // 16, 2, 64, 8) and wp.dtype == np.uint16
+  assert wp.nbytes == kp // 32 * np_cols * 128              # same chunk size as the fp32 layout
+  hi, lo = packing.unpack_weight_split(wp, k, n, chained=chained)
+  want_hi, want_lo = packing.split_f16(w)
+  np.testing.assert_array_equal(hi, want_hi.astype(np.float32))
+  np.testing.assert_array_equal(lo, want_lo.astype(np.float32))
+  # explicit lane map of include/gcast.h: lane 16 g + n, element j
+  v = wp.view(np.float16)
+  for (c, nb, g, nn, j) in [(0, 0, 0, 0, 0), (kp // 32 - 1, np_cols // 16 - 1, 3, 15, 7), (0, 1, 2, 5, 3),
+                            (0, 1, 2, 5, 4)]:
+    kk = 32 * c + ((4 * g + j if j < 4 else 16 + 4 * g + j - 4) if chained else 8 * g + j)
+    col = 16 * nb + nn
+    want = want_hi[kk, col] if (kk < k and col < n) else np.float16(0)
+    assert v[c, nb, 0, 16 * g + nn, j] == want
+
+
+def test_split_product_error_is_fp32_class():
+  """Numpy emulation of the GC_PREC_F16X3 arithmetic (three half products, wide accumulation):
+  the representation error of x_hi.w_hi + x_lo.w_hi + x_hi.w_lo is ~1e-7 relative."""
+  rng = np.random.default_rng(1)
+  x = rng.standard_normal((64, 512)).astype(np.float32)
+  w = (rng.standard_normal((512, 512)) / np.sqrt(512)).astype(np.float32)
+  xh, xl = [a.astype(np.float64) for a in packing.split_f16(x)]
+  wh, wl = [a.astype(np.float64) for a in packing.split_f16(w)]
+  got = xh @ wh + xl @ wh + xh @ wl
+  want = x.astype(np.float64) @ w
+  assert np.linalg.norm(got - want) / np.linalg.norm(want) < 6e-7   # fp32 sgemm: 3e-7

@@ -1,0 +1,106 @@
+"""GPU parity of the Dataset-level path: GraphCast.__call__ (reference graphcast.py:298-329)
+under normalization.InputsAndResiduals + rollout.chunked_prediction, with the state kept in
+HBM between steps (torch-backed datasets), against the same wrappers around a Predictor whose
+step is the float64 CPU oracle.  Tolerance: rel-RMSE <= 1e-4 (BASELINE.json) after 3
+autoregressive steps; asserted 5e-5."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from graphcast_amd import graphcast as gc          # noqa: E402
+from graphcast_amd import model_utils              # noqa: E402
+from graphcast_amd import normalization            # noqa: E402
+from graphcast_amd import predictor_base           # noqa: E402
+from graphcast_amd import rollout                  # noqa: E402
+from graphcast_amd import synthetic                # noqa: E402
+from graphcast_amd import xarray_lite as xarray    # noqa: E402
+from oracle import graphcast as ogc                # noqa: E402
+from oracle import params as oparams               # noqa: E402
+
+RES, MESH, STEPS = 6.0, 2, 2
+LAT = np.arange(-90, 90 + RES / 2, RES)
+LON = np.arange(0, 360, RES)
+
+
+class OraclePredictor(predictor_base.Predictor):
+  """The reference's GraphCast.__call__ with the float64 oracle as the step."""
+
+  def __init__(self, params, graphs):
+    self.params, self.graphs = params, graphs
+
+  def __call__(self, inputs, targets_template, forcings, **kw):
+    x = xarray.concat([model_utils.dataset_to_stacked(inputs),
+                       model_utils.dataset_to_stacked(forcings)], dim="channels")
+    x = np.asarray(model_utils.lat_lon_to_leading_axes(x).data, np.float64)
+    y = ogc.forward(self.params, self.graphs, x.reshape((-1,) + x.shape[2:]), steps=STEPS)
+    y = xarray.DataArray(y.reshape((len(LAT), len(LON)) + y.shape[1:]),
+                         dims=("lat", "lon", "batch", "channels"))
+    return model_utils.stacked_to_dataset(model_utils.restore_leading_axes(y).variable,
+                                          targets_template)
+
+
+@pytest.fixture(scope="module")
+def setup():
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  cfg = gc.ModelConfig(resolution=RES, mesh_size=MESH, latent_size=512, gnn_msg_steps=STEPS,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
+  params = oparams.init_params(c_in, c_out, 512, STEPS, seed=1, nontrivial=True)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params)
+  graphs = ogc.build_graphs(LAT, LON, MESH)
+  return model, OraclePredictor(params, graphs)
+
+
+def _rel(a, b):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_dataset_call_host_and_device_inputs(setup):
+  model, oracle = setup
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, batch=2, seed=5)
+  want = oracle(inputs, template, forcings)
+  got_host = model(inputs, template, forcings)
+  dev = lambda ds: synthetic.to_device(ds, "cuda:0")
+  got_dev = model(dev(inputs), template, dev(forcings))
+  for k in template.keys():
+    assert got_host[k].dims == template[k].dims
+    assert isinstance(got_host[k].data, np.ndarray)
+    assert torch.is_tensor(got_dev[k].data) and got_dev[k].data.is_cuda
+    assert _rel(got_host[k].values, want[k].values) < 2e-5, k
+    np.testing.assert_array_equal(got_dev[k].values, got_host[k].values)
+
+
+def test_normalised_rollout_resident_in_hbm(setup):
+  model, oracle = setup
+  n_steps = 3
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, num_target_steps=n_steps,
+                                                      seed=7)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  wrap = lambda p: normalization.InputsAndResiduals(p, std, mean, dstd)
+  ref = wrap(oracle)
+  want = rollout.chunked_prediction(lambda rng, **kw: ref(**kw), None, inputs, template, forcings)
+  dut = wrap(model)
+  put = lambda ds: synthetic.to_device(ds, "cuda:0")
+  chunks = list(rollout.chunked_prediction_generator(
+      lambda rng, **kw: dut(**kw), None, inputs, template, 1, forcings, device_put_fn=put))
+  assert len(chunks) == n_steps
+  assert all(c["temperature"].data.is_cuda for c in chunks)          # state never left the device
+  got = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
+                                   device_put_fn=put)
+  worst = 0.0
+  for k in template.keys():
+    assert got[k].shape == want[k].shape
+    for t in range(n_steps):
+      tax = got[k].dims.index("time")
+      e = _rel(np.take(got[k].values, t, axis=tax), np.take(want[k].values, t, axis=tax))
+      worst = max(worst, e)
+  print(f"3-step normalised rollout: worst per-variable per-step rel-RMSE {worst:.2e}")
+  assert worst < 5e-5
+  np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)

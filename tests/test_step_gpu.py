@@ -20,8 +20,8 @@ def rel_rmse(got, want):
   return float(np.linalg.norm(np.asarray(got, np.float64) - want) / np.linalg.norm(want))
 
 
-@pytest.fixture(scope="module")
-def small():
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def small(request):
   if not torch.cuda.is_available():
     pytest.fail("GPU test selected but no GPU is visible")
   res, mesh_size, steps = 4.0, 3, 3
@@ -31,9 +31,10 @@ def small():
                        hidden_layers=1, radius_query_fraction_edge_length=0.6)
   c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
   params = oparams.init_params(c_in, c_out, 512, steps, seed=1, nontrivial=True)
-  model = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(lat, lon)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params,
+                       precision=request.param).init_from_coordinates(lat, lon)
   graphs = ogc.build_graphs(lat, lon, mesh_size)
-  return dict(model=model, graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
+  return dict(model=model, precision=request.param, graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
 
 
 def test_product_graphs_equal_oracle_graphs(small):
@@ -54,7 +55,7 @@ def test_step_matches_oracle(small, batch):
   got = y.cpu().numpy()
   assert got.shape == want.shape == (small["graphs"]["n_grid"], batch, small["c_out"])
   err = rel_rmse(got, want)
-  print(f"step rel-RMSE vs float64 oracle (batch={batch}): {err:.3e}")
+  print(f"step rel-RMSE vs float64 oracle (batch={batch}, {small['precision']}): {err:.3e}")
   assert np.isfinite(got).all()
   assert err <= REL_RMSE_TOL
   for b in range(batch):                        # per batch element too
@@ -83,7 +84,8 @@ def test_missing_params_and_bad_shapes_raise(small):
     small["model"].forward_grid_node_features(torch.zeros((5, 1, 183), device="cuda:0"))
 
 
-def test_step_matches_reference_golden_vectors(golden_dir):
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_step_matches_reference_golden_vectors(golden_dir, precision):
   """HIP path vs tests/golden/gnn_latent512.npz = the reference's own graphcast.py /
   deep_typed_graph_net.py / typed_graph_net.py executed (float64) on numpy stand-ins for
   haiku / jraph / jax (tests/golden/make_golden.py).  fp32 tolerance: rel-RMSE <= 2e-5."""
@@ -92,9 +94,10 @@ def test_step_matches_reference_golden_vectors(golden_dir):
   res, mesh_size = float(z["config"][0]), int(z["config"][1])
   cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=steps,
                        hidden_layers=1, radius_query_fraction_edge_length=0.6)
-  model = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(z["lat"], z["lon"])
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params,
+                       precision=precision).init_from_coordinates(z["lat"], z["lon"])
   y = model.forward_grid_node_features(torch.from_numpy(z["x"]).to("cuda:0"))
   torch.cuda.synchronize()
   err = rel_rmse(y.cpu().numpy(), z["out"])
-  print(f"step rel-RMSE vs reference-executed golden vectors: {err:.3e}")
+  print(f"step rel-RMSE vs reference-executed golden vectors ({precision}): {err:.3e}")
   assert err <= REL_RMSE_TOL
