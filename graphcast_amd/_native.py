@@ -27,7 +27,7 @@ class RowMlpDesc(ctypes.Structure):
   """struct gc_rowmlp_desc (include/gcast.h) -- field order must match exactly."""
   _fields_ = [
       ("mode", ctypes.c_int), ("prec", ctypes.c_int), ("n_rows", ctypes.c_int),
-      ("reserved0", ctypes.c_int),
+      ("reserved0", ctypes.c_int), ("w1_scale", ctypes.c_float), ("w2_scale", ctypes.c_float),
       ("a0", _fp), ("lda0", ctypes.c_int), ("k0", ctypes.c_int),
       ("a1", _fp), ("lda1", ctypes.c_int), ("k1", ctypes.c_int),
       ("w1p", _fp),
@@ -56,22 +56,39 @@ class Op(ctypes.Structure):
   ]
 
 
-EXPORTS = ("gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
+class AdvanceDesc(ctypes.Structure):
+  """struct gc_advance_desc."""
+  _fields_ = [
+      ("n_rows", ctypes.c_int), ("c_in", ctypes.c_int), ("c_out", ctypes.c_int),
+      ("n_forc", ctypes.c_int),
+      ("x", _fp), ("y", _fp), ("f_cur", _fp), ("f_next", _fp),
+      ("src_x", _fp), ("ax", _fp), ("src_y", _fp), ("ay", _fp), ("src_f", _fp),
+      ("x_next", _fp),
+      ("p_src_x", _fp), ("p_ax", _fp), ("p_ay", _fp), ("p_b", _fp),
+      ("pred", _fp),
+  ]
+
+
+EXPORTS = ("gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
 
+# Build variants of the one source: "main" = the shipped library; "pipe1" = the split-f16 kernels
+# with the per-chunk barrier at the top of each chunk (GC_PIPE=1), kept as an A/B for profiling.
+VARIANTS = {"main": ("libgcast_hip.so", "-DGC_PIPE=2"), "pipe1": ("libgcast_hip_pipe1.so", "-DGC_PIPE=1")}
+
+
 def library_path(variant=None):
-  variant = variant or os.environ.get("GCAST_LIB_VARIANT", "glds")
-  name = {"glds": "libgcast_hip.so", "regs": "libgcast_hip_regs.so"}[variant]
-  return os.path.join(_CSRC, name)
+  variant = variant or os.environ.get("GCAST_LIB_VARIANT", "main")
+  return os.path.join(_CSRC, VARIANTS[variant][0])
 
 
 def build(force=False, verbose=False):
-  """Compiles csrc/gcast.hip for gfx950 with hipcc (both LDS-staging variants)."""
+  """Compiles csrc/gcast.hip for gfx950 with hipcc (all build variants)."""
   src = os.path.join(_CSRC, "gcast.hip")
   hdr = os.path.join(_INCLUDE, "gcast.h")
   newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
-  for variant, define in (("glds", "-DGC_STAGE_GLDS=1"), ("regs", "-DGC_STAGE_GLDS=0")):
+  for variant, (_, define) in VARIANTS.items():
     out = library_path(variant)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
       continue
@@ -102,6 +119,8 @@ def lib():
     l.gc_zero_rows.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_void_p]
     l.gc_prep_grid_input.argtypes = [ctypes.c_int] * 4 + [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp,
                                                           ctypes.c_void_p]
+    l.gc_advance_state.argtypes = [ctypes.POINTER(AdvanceDesc), ctypes.c_void_p]
+    l.gc_advance_state.restype = ctypes.c_int
     l.gc_run_program.argtypes = [ctypes.POINTER(Op), ctypes.c_int, ctypes.c_void_p]
     l.gc_time_program.argtypes = [ctypes.POINTER(Op), ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
@@ -111,7 +130,8 @@ def lib():
     l.gc_last_error.restype = ctypes.c_char_p
     l.gc_abi_sizeof.argtypes = [ctypes.c_int]
     l.gc_abi_sizeof.restype = ctypes.c_size_t
-    if (l.gc_abi_sizeof(0) != ctypes.sizeof(RowMlpDesc) or l.gc_abi_sizeof(1) != ctypes.sizeof(Op)):
+    if (l.gc_abi_sizeof(0) != ctypes.sizeof(RowMlpDesc) or l.gc_abi_sizeof(1) != ctypes.sizeof(Op)
+        or l.gc_abi_sizeof(2) != ctypes.sizeof(AdvanceDesc)):
       raise RuntimeError("ctypes struct layout does not match include/gcast.h "
                          f"({l.gc_abi_sizeof(0)}/{ctypes.sizeof(RowMlpDesc)}, "
                          f"{l.gc_abi_sizeof(1)}/{ctypes.sizeof(Op)}); rebuild the library")

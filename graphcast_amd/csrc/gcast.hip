@@ -18,6 +18,7 @@
 // read as conflict-free ds_read_b128 (slot index == n mod 16 within a lane group).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -28,12 +29,15 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-#ifndef GC_STAGE_GLDS
-#define GC_STAGE_GLDS 1
-#endif
 #ifndef GC_SCHED_PIN
 #define GC_SCHED_PIN 1
 #endif
+#ifndef GC_PIPE
+#define GC_PIPE 2        // split-f16 path: where the per-chunk barrier sits (see mma16_group)
+#endif
+#ifndef GC_EXP
+#define GC_EXP 0         // profiling experiments ONLY (scripts/kernel_probe.py; results are wrong):
+#endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA
 
 namespace {
 
@@ -60,15 +64,10 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 __device__ __forceinline__ void stage_piece(const float* __restrict__ gsrc, float* lds, int piece,
                                             int wave, int lane) {
   const int off = piece * 1024 + wave * 256;     // wave-uniform float offset of this 1 KiB piece
-#if GC_STAGE_GLDS
-  // LDS destination = wave-uniform base + lane * 16 B (linear image).
+  // LDS-DMA: destination = wave-uniform base + lane * 16 B (linear image), no VGPR round trip.
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)(gsrc + off + lane * 4),
       (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
-#else
-  const f4 v = *reinterpret_cast<const f4*>(gsrc + off + lane * 4);
-  *reinterpret_cast<f4*>(lds + off + lane * 4) = v;
-#endif
 }
 
 // Copies one whole K chunk of packed weights (8 * NP * 4 floats, contiguous) into LDS.
@@ -182,6 +181,10 @@ __device__ __forceinline__ void mma_chunk(f4 (&acc)[kNB], const float* wb, f4 b0
 // so two adjacent accumulator blocks (2c, 2c+1) are, after the split, the B operand of K step
 // c of the next layer ("chained" kmap, see gcast.h).
 __device__ __forceinline__ f4 mfma32h(u4 a, u4 b, f4 c) {
+#if GC_EXP & 4
+  c.x += __builtin_bit_cast(float, a.x ^ b.x);      // keeps the operands alive, no matrix core
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b),
                                                 c, 0, 0, 0);
 }
@@ -218,20 +221,32 @@ __device__ __forceinline__ void split8(f4 a, f4 b, u4& hi, u4& lo) {
 //   3. the 8 ds_read_b128 of group T+1's fragments,
 //   4. the lo.hi and hi.lo MFMAs, which cover the latency of 3.
 // Every accumulator sees its three dependent MFMAs four issue slots apart.
-template <int NBLK, int PIECES, int T>
-__device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const u4 (&ah)[4],
-                                            const u4 (&al)[4], u4 bh, u4 bl,
+//
+// GC_PIPE == 2 (default): the workgroup barrier that publishes the NEXT chunk sits INSIDE the
+// last group, between 2 and 3, and step 3 then requests the next chunk's first fragments: the
+// barrier and the LDS latency hide behind the last 8 MFMAs instead of opening a bubble at the
+// top of every chunk (with 16-cycle MFMAs a chunk is only ~1500 cycles).  All of the next
+// chunk's DMA is issued in the first kGroups-2 groups so that it has landed by then.  Safe with
+// two buffers: every wave has its last fragments of the current buffer in registers before the
+// barrier, and the DMA that overwrites that buffer is only issued after it.
+// GC_PIPE == 1: barrier + first fragment reads at the top of each chunk (the fp32 path's scheme).
+template <int NBLK, int PIECES, int T, bool NEXT>
+__device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const u4* wb_next,
+                                            const u4 (&ah)[4], const u4 (&al)[4], u4 (&oh)[4],
+                                            u4 (&ol)[4], u4 bh, u4 bl,
                                             const float* __restrict__ next_src, float* next_dst,
                                             int wave, int lane) {
   constexpr int kGroups = (NBLK + 3) / 4;
   constexpr int n0 = 4 * T;
   constexpr int cnt = NBLK - n0 < 4 ? NBLK - n0 : 4;
-  constexpr int kPpg = (PIECES + kGroups - 1) / kGroups;
+  constexpr int kDmaGroups = (GC_PIPE == 2 && kGroups > 2) ? kGroups - 2 : kGroups;
+  constexpr int kPpg = (PIECES + kDmaGroups - 1) / kDmaGroups;
   constexpr bool more = T + 1 < kGroups;
+  constexpr bool cross = !more && NEXT && GC_PIPE == 2;
   constexpr int cnt2 = more ? (NBLK - n0 - 4 < 4 ? NBLK - n0 - 4 : 4) : 0;
 #pragma unroll
   for (int p = 0; p < kPpg; ++p) {
-    if (T * kPpg + p < PIECES) stage_piece(next_src, next_dst, T * kPpg + p, wave, lane);
+    if (!(GC_EXP & 1) && T * kPpg + p < PIECES) stage_piece(next_src, next_dst, T * kPpg + p, wave, lane);
   }
 #if GC_SCHED_PIN
   __builtin_amdgcn_sched_barrier(0);
@@ -242,14 +257,23 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
   __builtin_amdgcn_sched_barrier(0);
 #endif
   u4 nh[4], nl[4];
+  if constexpr (cross) {
+    __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (q < cnt2) {
-      nh[q] = wb[(n0 + 4 + q) * 128];
-      nl[q] = wb[(n0 + 4 + q) * 128 + 64];
-    } else {
-      nh[q] = ah[q];
-      nl[q] = al[q];
+    for (int q = 0; q < 4; ++q) {
+      nh[q] = wb_next[q * 128];
+      nl[q] = wb_next[q * 128 + 64];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < cnt2 && !(GC_EXP & 2)) {
+        nh[q] = wb[(n0 + 4 + q) * 128];
+        nl[q] = wb[(n0 + 4 + q) * 128 + 64];
+      } else {
+        nh[q] = ah[q];
+        nl[q] = al[q];
+      }
     }
   }
 #if GC_SCHED_PIN
@@ -263,24 +287,41 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
   __builtin_amdgcn_sched_barrier(0);
 #endif
   if constexpr (more) {
-    mma16_group<NBLK, PIECES, T + 1>(acc, wb, nh, nl, bh, bl, next_src, next_dst, wave, lane);
+    mma16_group<NBLK, PIECES, T + 1, NEXT>(acc, wb, wb_next, nh, nl, oh, ol, bh, bl, next_src,
+                                           next_dst, wave, lane);
+  } else if constexpr (cross) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      oh[q] = nh[q];
+      ol[q] = nl[q];
+    }
   }
 }
 
-// acc[nb] += W-chunk(32 k) . B for nb < NBLK; `wbuf` = the chunk's LDS image, (bh, bl) the split
-// B operand; PIECES 1 KiB-per-wave pieces of the next chunk are DMA'd to next_dst meanwhile.
-template <int NBLK, int PIECES>
-__device__ __forceinline__ void mma16_chunk(f4 (&acc)[kNB], const float* wbuf, u4 bh, u4 bl,
-                                            const float* __restrict__ next_src, float* next_dst,
-                                            int wave, int lane) {
+// The first four n-blocks' fragments of the chunk image at `wbuf`.
+__device__ __forceinline__ void load_first_frags(const float* wbuf, int lane, u4 (&fh)[4], u4 (&fl)[4]) {
   const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
-  u4 ah[4], al[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    ah[q] = wb[(q < NBLK ? q : 0) * 128];
-    al[q] = wb[(q < NBLK ? q : 0) * 128 + 64];
+    fh[q] = wb[q * 128];
+    fl[q] = wb[q * 128 + 64];
   }
-  mma16_group<NBLK, PIECES, 0>(acc, wb, ah, al, bh, bl, next_src, next_dst, wave, lane);
+}
+
+// acc[nb] += W-chunk(32 k) . B for nb < NBLK.  `wbuf` = the chunk's LDS image, (bh, bl) the split
+// B operand; PIECES 1 KiB-per-wave pieces of the next chunk are DMA'd to `wnext` meanwhile.
+// (fh, fl): in = this chunk's first fragments; out (GC_PIPE == 2, NEXT) = the next chunk's.
+template <int NBLK, int PIECES, bool NEXT>
+__device__ __forceinline__ void mma16_chunk(f4 (&acc)[kNB], const float* wbuf, float* wnext,
+                                            u4 (&fh)[4], u4 (&fl)[4], u4 bh, u4 bl,
+                                            const float* __restrict__ next_src, int wave, int lane) {
+  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
+  const u4* wbn = reinterpret_cast<const u4*>(wnext) + lane;
+  if (GC_PIPE == 1) {
+    __syncthreads();      // this chunk landed; the previous chunk's readers are done
+    load_first_frags(wbuf, lane, fh, fl);
+  }
+  mma16_group<NBLK, PIECES, 0, NEXT>(acc, wb, wbn, fh, fl, fh, fl, bh, bl, next_src, wnext, wave, lane);
 }
 
 __device__ __forceinline__ float swish1(float x) {
@@ -298,31 +339,33 @@ __device__ __forceinline__ float group_sum4(float v) {
 // ---- pieces shared by the two arithmetic modes ----------------------------------------
 
 // Layer-1 accumulators start from the addends: b1 + d[row] + g0[idx0[row]] + g1[idx1[row]].
-__device__ __forceinline__ void init_addends(f4 (&acc)[kNB], const gc_rowmlp_desc& d, int rowc, int col0) {
+// `s` = the power of two the layer's packed weights carry (1 in fp32 mode): exact scaling.
+__device__ __forceinline__ void init_addends(f4 (&acc)[kNB], const gc_rowmlp_desc& d, int rowc, int col0,
+                                             float s) {
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
   if (d.b1) {
 #pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(d.b1 + nb * 16 + col0);
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += s * *reinterpret_cast<const f4*>(d.b1 + nb * 16 + col0);
   }
   if (d.d) {
     const float* p = d.d + (size_t)rowc * d.ldd + col0;
 #pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(p + nb * 16);
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += s * *reinterpret_cast<const f4*>(p + nb * 16);
   }
   if (d.g0) {
     int ix = d.idx0[rowc];
     ix = ix < 0 ? 0 : ix;
     const float* p = d.g0 + (size_t)ix * kD + col0;
 #pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(p + nb * 16);
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += s * *reinterpret_cast<const f4*>(p + nb * 16);
   }
   if (d.g1) {
     int ix = d.idx1[rowc];
     ix = ix < 0 ? 0 : ix;
     const float* p = d.g1 + (size_t)ix * kD + col0;
 #pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) acc[nb] += *reinterpret_cast<const f4*>(p + nb * 16);
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] += s * *reinterpret_cast<const f4*>(p + nb * 16);
   }
 }
 
@@ -475,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
   }
 
   f4 acc[kNB];
-  init_addends(acc, d, rowc, col0);
+  init_addends(acc, d, rowc, col0, 1.0f);
 
   // ---- layer 1: acc += A . W1, A rows streamed from global as B operands ---------
   if (n1 > 0) {
@@ -579,8 +622,16 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
   }
 
   f4 acc[kNB];
-  init_addends(acc, d, rowc, col0);
+  init_addends(acc, d, rowc, col0, d.w1_scale);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  u4 fh[4], fl[4];        // fragments of the next four n-blocks, carried across chunks
+  if (GC_PIPE == 2) {
+    __syncthreads();      // the chunk staged in the prologue
+    load_first_frags(smem, lane, fh, fl);
+  }
+  float* const buf0 = smem;
+  float* const buf1 = smem + kBufFloats;
 
   // ---- layer 1: the lane's 8 consecutive k of its row per chunk, split in registers ----
   if (n1 > 0) {
@@ -596,31 +647,34 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
     xn1 = xc1;
     u4 bh, bl;
     for (int c = 0; c + 1 < n1; ++c) {
-      __syncthreads();
       {
         const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
         xn0 = *reinterpret_cast<const f4*>(p);
         xn1 = *reinterpret_cast<const f4*>(p + 4);
       }
       split8(xc0, xc1, bh, bl);
-      mma16_chunk<kNB, kPieces1>(acc, smem + (q & 1) * kBufFloats, bh, bl,
-                                 w1p + (size_t)(c + 1) * kBufFloats,
-                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+      mma16_chunk<kNB, kPieces1, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl,
+                                       bh, bl, w1p + (size_t)(c + 1) * kBufFloats, wave_u, lane);
       xc0 = xn0;
       xc1 = xn1;
       ++q;
     }
-    __syncthreads();
     split8(xc0, xc1, bh, bl);
     if (kLinear) {
-      mma16_chunk<kNB, 0>(acc, smem + (q & 1) * kBufFloats, bh, bl, nullptr, nullptr, wave_u, lane);
+      mma16_chunk<kNB, 0, false>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl, bh, bl,
+                                 nullptr, wave_u, lane);
     } else {
-      mma16_chunk<kNB, kPieces2>(acc, smem + (q & 1) * kBufFloats, bh, bl, w2p,
-                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+      mma16_chunk<kNB, kPieces2, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl,
+                                       bh, bl, w2p, wave_u, lane);
     }
     ++q;
   }
 
+  {
+    const float inv1 = 1.0f / d.w1_scale;       // exact: a power of two
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] *= inv1;
+  }
   if (kLinear) {
     store_linear(acc, d, row, col0);
     return;
@@ -634,17 +688,16 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
 
   f4 o2[kNB];
 #pragma unroll
-  for (int nb = 0; nb < NB2; ++nb) o2[nb] = *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
+  for (int nb = 0; nb < NB2; ++nb) o2[nb] = d.w2_scale * *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
 #pragma unroll
   for (int cc = 0; cc < kD / 32; ++cc) {
-    __syncthreads();
     if (cc + 1 < kD / 32) {
-      mma16_chunk<NB2, kPieces2>(o2, smem + (q & 1) * kBufFloats, hh[cc], hl[cc],
-                                 w2p + (size_t)(cc + 1) * (8 * NP2 * 4),
-                                 smem + ((q + 1) & 1) * kBufFloats, wave_u, lane);
+      mma16_chunk<NB2, kPieces2, true>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl,
+                                       hh[cc], hl[cc], w2p + (size_t)(cc + 1) * (8 * NP2 * 4),
+                                       wave_u, lane);
     } else {
-      mma16_chunk<NB2, 0>(o2, smem + (q & 1) * kBufFloats, hh[cc], hl[cc], nullptr, nullptr,
-                          wave_u, lane);
+      mma16_chunk<NB2, 0, false>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl, hh[cc],
+                                 hl[cc], nullptr, wave_u, lane);
     }
     ++q;
   }
@@ -691,6 +744,37 @@ __global__ void prep_grid_input_kernel(int n_rows, int batch, int b, int c_in,
   }
 }
 
+// One wave per row; lanes stride over channels.  The per-channel tables (a few KiB) stay in
+// L1/K$; x / y rows are contiguous, so the gathered picks hit the lines the row read brought in.
+__global__ __launch_bounds__(256) void advance_state_kernel(const gc_advance_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.n_rows) return;
+  const float* x = d.x + (size_t)row * d.c_in;
+  const float* y = d.y + (size_t)row * d.c_out;
+  float* xn = d.x_next + (size_t)row * d.c_in;
+  for (int c = lane; c < d.c_in; c += 64) {
+    float v = 0.f;
+    const int sx = d.src_x[c], sy = d.src_y[c], sf = d.src_f[c];
+    if (sx >= 0) v = d.ax[c] * x[sx];
+    if (sy >= 0) v = fmaf(d.ay[c], y[sy], v);
+    if (sf >= 0) {
+      v += sf < d.n_forc ? d.f_cur[(size_t)row * d.n_forc + sf]
+                         : d.f_next[(size_t)row * d.n_forc + (sf - d.n_forc)];
+    }
+    xn[c] = v;
+  }
+  if (d.pred) {
+    float* p = d.pred + (size_t)row * d.c_out;
+    for (int k = lane; k < d.c_out; k += 64) {
+      float v = fmaf(d.p_ay[k], y[k], d.p_b[k]);
+      const int sx = d.p_src_x[k];
+      if (sx >= 0) v = fmaf(d.p_ax[k], x[sx], v);
+      p[k] = v;
+    }
+  }
+}
+
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -731,9 +815,21 @@ bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; 
 
 extern "C" {
 
+static bool pow2_or_unset(float s) {
+  if (s == 0.f) return true;
+  int e = 0;
+  return s > 0.f && std::frexp(s, &e) == 0.5f;
+}
+
 int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (!dp) return fail(GC_EINVAL, "gc_rowmlp: null descriptor");
-  const gc_rowmlp_desc& d = *dp;
+  gc_rowmlp_desc d = *dp;
+  if (!pow2_or_unset(d.w1_scale) || !pow2_or_unset(d.w2_scale))
+    return fail(GC_EINVAL, "gc_rowmlp: w1_scale / w2_scale must be powers of two");
+  if (d.w1_scale == 0.f) d.w1_scale = 1.f;
+  if (d.w2_scale == 0.f) d.w2_scale = 1.f;
+  if (d.prec == GC_PREC_F32 && (d.w1_scale != 1.f || d.w2_scale != 1.f))
+    return fail(GC_EINVAL, "gc_rowmlp: weight scales are a GC_PREC_F16X3 feature");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
   if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3) return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
@@ -806,6 +902,22 @@ int gc_prep_grid_input(int n_rows, int batch, int b, int c_in, const float* x, i
   return check_launch("prep_grid_input_kernel");
 }
 
+int gc_advance_state(const gc_advance_desc* dp, void* stream) {
+  if (!dp) return fail(GC_EINVAL, "gc_advance_state: null descriptor");
+  const gc_advance_desc& d = *dp;
+  if (d.n_rows <= 0 || d.c_in <= 0 || d.c_out <= 0 || d.n_forc < 0)
+    return fail(GC_EINVAL, "gc_advance_state: bad sizes");
+  if (!d.x || !d.y || !d.x_next || !d.src_x || !d.ax || !d.src_y || !d.ay || !d.src_f)
+    return fail(GC_EINVAL, "gc_advance_state: null pointer");
+  if (d.x == d.x_next) return fail(GC_EINVAL, "gc_advance_state: x_next must not alias x");
+  if (d.n_forc > 0 && (!d.f_cur || !d.f_next)) return fail(GC_EINVAL, "gc_advance_state: forcings missing");
+  if (d.pred && (!d.p_src_x || !d.p_ax || !d.p_ay || !d.p_b))
+    return fail(GC_EINVAL, "gc_advance_state: prediction tables missing");
+  hipLaunchKernelGGL(advance_state_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d);
+  return check_launch("advance_state_kernel");
+}
+
 static int run_op(const gc_op& op, void* stream) {
   switch (op.kind) {
     case GC_OP_ROWMLP:
@@ -857,17 +969,16 @@ int gc_time_program(const gc_op* ops, int n_ops, int iters, float* h_ms, void* s
 }
 
 size_t gc_abi_sizeof(int what) {
-  return what == 0 ? sizeof(gc_rowmlp_desc) : what == 1 ? sizeof(gc_op) : 0;
+  return what == 0 ? sizeof(gc_rowmlp_desc) : what == 1 ? sizeof(gc_op)
+         : what == 2 ? sizeof(gc_advance_desc) : 0;
 }
 
 const char* gc_last_error(void) { return g_err; }
 
+#define GC_STR2(x) #x
+#define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
-#if GC_STAGE_GLDS
-  return "gfx950;stage=glds;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32";
-#else
-  return "gfx950;stage=regs;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32";
-#endif
+  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32;pipe=" GC_STR(GC_PIPE);
 }
 
 }  // extern "C"

@@ -40,6 +40,17 @@ TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, en
             dec_out=12, fixup=13)
 
 
+class _PW:
+  """A packed weight image on the device + the power of two it was multiplied by."""
+  __slots__ = ("t", "scale")
+
+  def __init__(self, t, scale=1.0):
+    self.t, self.scale = t, float(scale)
+
+  def data_ptr(self):
+    return self.t.data_ptr()
+
+
 class _Mlp:
   """Packed device copy of one `<stem>_mlp` (+ `<stem>_layer_norm`)."""
 
@@ -57,22 +68,28 @@ class _Mlp:
       # (hi, lo) fp16 images; layer 1 reads rows from memory (natural K order), layer 2 is fed by
       # layer 1's accumulator registers (chained K order) -- include/gcast.h.  Stored as int16
       # bit patterns: the kernels only ever see the raw chunk image.
-      pack1 = lambda w: packing.pack_weight_split(w).view(np.int16)
-      pack2 = lambda w, np_cols: packing.pack_weight_split(w, np_cols=np_cols, chained=True).view(np.int16)
+      def pack1(w):
+        sc = packing.choose_weight_scale(w)
+        return _PW(up(packing.pack_weight_split(w, scale=sc).view(np.int16)), sc)
+
+      def pack2(w, np_cols):
+        sc = packing.choose_weight_scale(w)
+        return _PW(up(packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc)
+                      .view(np.int16)), sc)
     else:
-      pack1 = packing.pack_weight
-      pack2 = lambda w, np_cols: packing.pack_weight(w, np_cols=np_cols)
+      pack1 = lambda w: _PW(up(packing.pack_weight(w)))
+      pack2 = lambda w, np_cols: _PW(up(packing.pack_weight(w, np_cols=np_cols)))
     self.k_in = w1.shape[0]
     self.n_out = w2.shape[1]
     # W1 either whole, or split into named row blocks of 512 (concat order)
     if split is None:
-      self.w1 = up(pack1(w1))
+      self.w1 = pack1(w1)
       self.k1p = packing.round_up(w1.shape[0], packing.K_CHUNK)
     else:
       assert w1.shape[0] == D * len(split), (stem, w1.shape, split)
-      self.w1 = {name: up(pack1(w1[j * D:(j + 1) * D])) for j, name in enumerate(split)}
+      self.w1 = {name: pack1(w1[j * D:(j + 1) * D]) for j, name in enumerate(split)}
     self.b1 = up(b1)
-    self.w2 = up(pack2(w2, np2))
+    self.w2 = pack2(w2, np2)
     self.b2 = up(packing.pad_vector(b2, np2))
     self.scale = self.offset = None
     if f"{stem}_layer_norm" in params:
@@ -140,10 +157,12 @@ class StepEngine:
     ds.a0, ds.k0, ds.lda0 = nat.ptr(a0), k0, (lda0 if lda0 is not None else (a0.shape[1] if a0 is not None else 0))
     ds.a1, ds.k1, ds.lda1 = nat.ptr(a1), k1, (lda1 if lda1 is not None else (a1.shape[1] if a1 is not None else 0))
     ds.w1p = nat.ptr(w1p)
+    ds.w1_scale = w1p.scale if w1p is not None else 1.0
     ds.d, ds.ldd = nat.ptr(d), (d.shape[1] if d is not None else 0)
     ds.g0, ds.idx0, ds.g1, ds.idx1 = nat.ptr(g0), nat.ptr(idx0), nat.ptr(g1), nat.ptr(idx1)
     ds.b1 = nat.ptr(b1)
     ds.w2p, ds.b2, ds.n2 = nat.ptr(w2p), nat.ptr(b2), n2
+    ds.w2_scale = w2p.scale if w2p is not None else 1.0
     if ln is not None:
       ds.ln_scale, ds.ln_offset = nat.ptr(ln[0]), nat.ptr(ln[1])
     ds.res, ds.ldres = nat.ptr(res), (res.shape[1] if res is not None else 0)

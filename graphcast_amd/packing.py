@@ -62,12 +62,27 @@ def _kmap(chained):
   return 8 * g + j
 
 
-def pack_weight_split(w, np_cols=LATENT, chained=False):
+def choose_weight_scale(w):
+  """Power of two s such that rms(s w) ~ 0.5 and max|s w| <= 2^14: the lo half fp16(sw - hi) of
+  a typical weight is then a NORMAL fp16 number (fp16 subnormals below 2^-14 have an absolute
+  spacing of 2^-24, which would leave weights of ~1e-3 with only ~17 good bits)."""
+  w = np.asarray(w, dtype=np.float64)
+  rms = float(np.sqrt(np.mean(w * w))) if w.size else 0.0
+  top = float(np.abs(w).max()) if w.size else 0.0
+  if not np.isfinite(top) or rms == 0.0:
+    return 1.0
+  k = int(np.round(-1.0 - np.log2(rms)))
+  k = min(k, int(np.floor(14.0 - np.log2(top))))
+  return float(2.0 ** max(min(k, 24), -24))
+
+
+def pack_weight_split(w, np_cols=LATENT, chained=False, scale=1.0):
   """[K, N] float32 -> uint16 [ceil32(K)/32, np_cols/16, 2, 64, 8]: the GC_PREC_F16X3 layout of
-  include/gcast.h.  Entry [c, nb, part, 16 g + n, j] = part(hi|lo) of w[32 c + kmap(g, j)][16 nb + n];
+  include/gcast.h.  Entry [c, nb, part, 16 g + n, j] = part(hi|lo) of s*w[32 c + kmap(g, j)][16 nb + n];
   ``chained`` selects the K permutation of a layer fed by the previous layer's accumulator
-  registers (layer 2) instead of by rows read from memory (layer 1)."""
-  w = np.asarray(w, dtype=np.float32)
+  registers (layer 2) instead of by rows read from memory (layer 1); ``scale`` (a power of two,
+  see ``choose_weight_scale``) goes into gc_rowmlp_desc.w1_scale / w2_scale."""
+  w = np.asarray(w, dtype=np.float32) * np.float32(scale)
   k, n = w.shape
   if n > np_cols:
     raise ValueError(f"weight has {n} columns, packed layout holds {np_cols}")

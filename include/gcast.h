@@ -36,7 +36,9 @@
  *   chained (layer 2, rows are layer 1's accumulator registers):
  *                                              32*c + 4*g + j        (j < 4)
  *                                              32*c + 16 + 4*g + j-4 (j >= 4)
- * Chunk size in bytes is the same as in the fp32 layout (NP * 128).
+ * Chunk size in bytes is the same as in the fp32 layout (NP * 128).  The whole matrix may be
+ * pre-multiplied by a power of two (gc_rowmlp_desc.w1_scale / w2_scale) so that lo = fp16(w - hi)
+ * of a typical weight is a normal fp16 number (fp16 subnormals have an ABSOLUTE spacing of 2^-24).
  */
 #ifndef GCAST_H_
 #define GCAST_H_
@@ -96,6 +98,11 @@ typedef struct gc_rowmlp_desc {
   int prec;                /* enum gc_precision: selects the layout w1p / w2p are packed in */
   int n_rows;              /* rows to process */
   int reserved0;           /* keeps the pointers below 8-byte aligned; must be 0 */
+  /* Power-of-two factors the packed weights were multiplied by (GC_PREC_F16X3: chosen at pack
+   * time so that the lo halves of typical weights are NORMAL fp16 numbers; the kernel scales the
+   * layer's addends by the same factor and the accumulators by its inverse -- all exact).
+   * Must be 1 (or 0 = unset) for GC_PREC_F32. */
+  float w1_scale, w2_scale;
   /* layer-1 GEMM sources (row-major, 16-byte aligned rows); k0,k1 multiples of 32, may be 0 */
   const float* a0; int lda0; int k0;
   const float* a1; int lda1; int k1;
@@ -142,6 +149,37 @@ int gc_prep_grid_input(int n_rows, int batch, int b, int c_in, const float* x,
                        int n_struct, const float* node_struct, int kp, float* xin,
                        void* stream);
 
+/* One autoregressive state advance, entirely on the device: builds the NORMALISED stacked
+ * inputs of step s+1 from those of step s, the step's normalised output and the forcings,
+ * and (optionally) the DE-normalised prediction of step s.  Fuses, per channel,
+ *   - the rolling window of rollout._get_next_inputs (utils/rollout.py:581-604) /
+ *     autoregressive.Predictor._update_inputs (utils/autoregressive.py:114-125),
+ *   - InputsAndResiduals' un-normalise + residual add and the re-normalisation of the next
+ *     call (utils/normalization.py:113-132,148-160): in normalised space
+ *         x'_last = x_last + y * (diffs_stddev / stddev),
+ *   - the Dataset <-> stacked-channel round trip of graphcast.py:680-723 (never materialised).
+ * Every input channel c of the next state is an affine pick:
+ *   x_next[r,c] = ax[c]*x[r,src_x[c]] + ay[c]*y[r,src_y[c]] + f[r,src_f[c]]   (src < 0: term absent)
+ * with f = [f_cur | f_next] (normalised forcings at the time just predicted / at the next
+ * target time, n_forc channels each); and every output channel k
+ *   pred[r,k] = p_ay[k]*y[r,k] + p_ax[k]*x[r,p_src_x[k]] + p_b[k].
+ * x_next must not alias x.  Rows = grid nodes x batch.  HBM-bound. */
+typedef struct gc_advance_desc {
+  int n_rows, c_in, c_out, n_forc;
+  const float* x;        /* [n_rows, c_in]  normalised stacked inputs of this step */
+  const float* y;        /* [n_rows, c_out] normalised step output */
+  const float* f_cur;    /* [n_rows, n_forc] or NULL */
+  const float* f_next;   /* [n_rows, n_forc] or NULL */
+  const int* src_x; const float* ax;   /* [c_in] */
+  const int* src_y; const float* ay;   /* [c_in] */
+  const int* src_f;                    /* [c_in] index into [f_cur | f_next] */
+  float* x_next;         /* [n_rows, c_in] */
+  const int* p_src_x; const float* p_ax; const float* p_ay; const float* p_b;   /* [c_out] */
+  float* pred;           /* [n_rows, c_out] de-normalised prediction, or NULL */
+} gc_advance_desc;
+
+int gc_advance_state(const gc_advance_desc* desc, void* stream);
+
 /* A recorded sequence of launches = one encode-process-decode step
  * (graphcast.py:306-323 between _inputs_to_grid_node_features and
  * _grid_node_outputs_to_prediction). */
@@ -166,7 +204,7 @@ int gc_run_program(const gc_op* h_ops, int n_ops, void* stream);
  * Synchronises the stream.  Not used on the product path. */
 int gc_time_program(const gc_op* h_ops, int n_ops, int iters, float* h_ms, void* stream);
 
-/* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for what == 1, 0 otherwise:
+/* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for 1, sizeof(gc_advance_desc) for 2, 0 otherwise:
  * lets a foreign-language binding verify its struct layout at load time. */
 size_t gc_abi_sizeof(int what);
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box session: smoke, GPU parity tests (both LDS-staging variants if needed),
+# One GPU-box session: smoke, GPU parity tests (second build variant if the first fails),
 # bench line, rocprofv3 kernel trace.  Everything is logged under gpurun_out/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -12,17 +12,17 @@ echo "== smoke" | tee "$OUT/summary.txt"
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
 echo "smoke rc=$?" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
 
-echo "== pytest -m gpu (glds)" | tee -a "$OUT/summary.txt"
+echo "== pytest -m gpu (main)" | tee -a "$OUT/summary.txt"
 timeout 1200 python -m pytest tests -m gpu -q --timeout=600 > "$OUT/pytest_gpu.log" 2>&1
 RC=$?
 echo "pytest rc=$RC" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
 if [ $RC -ne 0 ]; then
-  echo "== pytest -m gpu (regs variant)" | tee -a "$OUT/summary.txt"
-  GCAST_LIB_VARIANT=regs timeout 1200 python -m pytest tests -m gpu -q -rA --timeout=600 > "$OUT/pytest_gpu_regs.log" 2>&1
-  echo "pytest(regs) rc=$?" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest_gpu_regs.log" | tee -a "$OUT/summary.txt"
-  if [ "${FALLBACK_TO_REGS:-1}" = "1" ] && tail -1 "$OUT/pytest_gpu_regs.log" | grep -q passed && ! tail -1 "$OUT/pytest_gpu_regs.log" | grep -q failed; then
-    export GCAST_LIB_VARIANT=regs
-    echo "continuing with GCAST_LIB_VARIANT=regs" | tee -a "$OUT/summary.txt"
+  echo "== pytest -m gpu (pipe1 variant)" | tee -a "$OUT/summary.txt"
+  GCAST_LIB_VARIANT=pipe1 timeout 1200 python -m pytest tests -m gpu -q -rA --timeout=600 > "$OUT/pytest_gpu_pipe1.log" 2>&1
+  echo "pytest(pipe1) rc=$?" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest_gpu_pipe1.log" | tee -a "$OUT/summary.txt"
+  if [ "${FALLBACK_TO_PIPE1:-1}" = "1" ] && tail -1 "$OUT/pytest_gpu_pipe1.log" | grep -q passed && ! tail -1 "$OUT/pytest_gpu_pipe1.log" | grep -q failed; then
+    export GCAST_LIB_VARIANT=pipe1
+    echo "continuing with GCAST_LIB_VARIANT=pipe1" | tee -a "$OUT/summary.txt"
   fi
 fi
 

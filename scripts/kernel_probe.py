@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Times single gc_rowmlp launches (shapes of the 0.25 deg step) for several builds of
+csrc/gcast.hip, including profiling-only experiment builds (-DGC_EXP=...: results wrong,
+timing informative) compiled on the spot into /tmp.  GPU box only.
+
+    python scripts/kernel_probe.py [--out gpurun_out/probe.json]
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphcast_amd import _native as nat      # noqa: E402
+from graphcast_amd import packing             # noqa: E402
+
+D = 512
+
+
+def build(tag, defines):
+  out = f"/tmp/libgcast_{tag}.so"
+  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", *defines,
+         "-I", os.path.join(ROOT, "include"), "-shared", "-fPIC",
+         os.path.join(ROOT, "graphcast_amd", "csrc", "gcast.hip"), "-o", out]
+  subprocess.run(cmd, check=True)
+  lib = ctypes.CDLL(out)
+  lib.gc_rowmlp.argtypes = [ctypes.POINTER(nat.RowMlpDesc), ctypes.c_void_p]
+  lib.gc_rowmlp.restype = ctypes.c_int
+  lib.gc_last_error.restype = ctypes.c_char_p
+  return lib
+
+
+def time_launch(lib, d, iters=8):
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  for _ in range(2):
+    rc = lib.gc_rowmlp(ctypes.byref(d), stream)
+    assert rc == 0, lib.gc_last_error()
+  torch.cuda.synchronize()
+  t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0.record()
+  for _ in range(iters):
+    lib.gc_rowmlp(ctypes.byref(d), stream)
+  t1.record()
+  torch.cuda.synchronize()
+  return t0.elapsed_time(t1) / iters
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "probe.json"))
+  ap.add_argument("--prec", default="f16x3")
+  args = ap.parse_args()
+  dev = torch.device("cuda:0")
+  rng = np.random.default_rng(0)
+  split = args.prec == "f16x3"
+  up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+  w = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+  if split:
+    w1 = up(packing.pack_weight_split(w).view(np.int16))
+    w2 = up(packing.pack_weight_split(w, chained=True).view(np.int16))
+    w1b = up(packing.pack_weight_split(np.concatenate([w, w])).view(np.int16))
+  else:
+    w1, w2, w1b = up(packing.pack_weight(w)), up(packing.pack_weight(w)), up(packing.pack_weight(np.concatenate([w, w])))
+  vec = up(np.zeros(D, np.float32))
+  one = up(np.ones(D, np.float32))
+  n_mesh = 40962
+  recv = np.repeat(np.arange(n_mesh), 8)
+  send = rng.integers(0, n_mesh, len(recv))
+  pk = packing.pack_edges(send, recv, n_mesh)
+  n_e = pk.n_rows
+  e = torch.randn((n_e, D), device=dev)
+  tab_s, tab_r = torch.randn((n_mesh, D), device=dev), torch.randn((n_mesh, D), device=dev)
+  agg = torch.empty((n_mesh, D), device=dev)
+  partial = torch.empty((2 * n_e // 64, D), device=dev)
+  snd, rcv, flags = up(pk.senders), up(pk.receivers), up(pk.tile_flags)
+  n_g = 1038240
+  hg = torch.randn((n_g, D), device=dev)
+  og = torch.empty((n_g, D), device=dev)
+  prec = nat.PRECISIONS[args.prec]
+
+  def desc(mode, n_rows):
+    d = nat.RowMlpDesc()
+    d.mode, d.n_rows, d.prec = mode, n_rows, prec
+    return d
+
+  def proc_edge():
+    d = desc(nat.MODE_MLP_LN, n_e)
+    d.a0, d.lda0, d.k0, d.w1p, d.b1 = e.data_ptr(), D, D, w1.data_ptr(), vec.data_ptr()
+    d.g0, d.idx0, d.g1, d.idx1 = tab_s.data_ptr(), snd.data_ptr(), tab_r.data_ptr(), rcv.data_ptr()
+    d.w2p, d.b2, d.n2 = w2.data_ptr(), vec.data_ptr(), D
+    d.ln_scale, d.ln_offset = one.data_ptr(), vec.data_ptr()
+    d.res, d.ldres, d.out, d.ldo = e.data_ptr(), D, e.data_ptr(), D
+    d.seg, d.tile_flags, d.agg, d.partial = rcv.data_ptr(), flags.data_ptr(), agg.data_ptr(), partial.data_ptr()
+    return d, 32, n_e
+
+  def gemm_only_mlp():        # MLP_LN on the same rows without gathers / residual / segment-sum
+    d = desc(nat.MODE_MLP_LN, n_e)
+    d.a0, d.lda0, d.k0, d.w1p, d.b1 = e.data_ptr(), D, D, w1.data_ptr(), vec.data_ptr()
+    d.w2p, d.b2, d.n2 = w2.data_ptr(), vec.data_ptr(), D
+    d.ln_scale, d.ln_offset = one.data_ptr(), vec.data_ptr()
+    d.out, d.ldo = agg.data_ptr(), 0          # every row stores to the same 2 KiB: no HBM write stream
+    return d, 32, n_e
+
+  def linear_grid():
+    d = desc(nat.MODE_LINEAR, n_g)
+    d.a0, d.lda0, d.k0, d.w1p = hg.data_ptr(), D, D, w1.data_ptr()
+    d.out, d.ldo = og.data_ptr(), D
+    return d, 16, n_g
+
+  def node_grid():            # dec_node-like: [h | agg] (K = 1024) -> MLP -> LN -> residual
+    d = desc(nat.MODE_MLP_LN, n_g)
+    d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = hg.data_ptr(), D, D, og.data_ptr(), D, D
+    d.w1p, d.b1 = w1b.data_ptr(), vec.data_ptr()
+    d.w2p, d.b2, d.n2 = w2.data_ptr(), vec.data_ptr(), D
+    d.ln_scale, d.ln_offset = one.data_ptr(), vec.data_ptr()
+    d.res, d.ldres, d.out, d.ldo = hg.data_ptr(), D, hg.data_ptr(), D
+    return d, 48, n_g
+
+  shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, linear_grid=linear_grid, node_grid=node_grid)
+  builds = [("pipe2", ["-DGC_PIPE=2"]), ("pipe1", ["-DGC_PIPE=1"]),
+            ("pipe2_nodma", ["-DGC_PIPE=2", "-DGC_EXP=1"]),
+            ("pipe2_noreads", ["-DGC_PIPE=2", "-DGC_EXP=2"]),
+            ("pipe2_nomfma", ["-DGC_PIPE=2", "-DGC_EXP=4"]),
+            ("pipe2_nodma_noreads", ["-DGC_PIPE=2", "-DGC_EXP=3"]),
+            ("pipe2_nosched", ["-DGC_PIPE=2", "-DGC_SCHED_PIN=0"])]
+  only_b = os.environ.get("PROBE_BUILDS")
+  only_s = os.environ.get("PROBE_SHAPES")
+  if only_b:
+    builds = [b for b in builds if b[0] in only_b.split(",")]
+  if only_s:
+    shapes = {k: v for k, v in shapes.items() if k in only_s.split(",")}
+  results = {}
+  for tag, defines in builds:
+    lib = build(tag, defines)
+    row = {}
+    for name, make in shapes.items():
+      d, chunks, rows = make()
+      ms = time_launch(lib, d)
+      tiles_per_cu = (rows + 63) // 64 / 256.0
+      row[name] = {"ms": round(ms, 4), "chunks_per_tile": chunks,
+                   "kcycles_per_chunk_at_2.4GHz": round(ms * 1e-3 * 2.4e9 / tiles_per_cu / chunks / 1e3, 2)}
+    results[tag] = row
+    print(tag, json.dumps(row), flush=True)
+  os.makedirs(os.path.dirname(args.out), exist_ok=True)
+  with open(args.out, "w") as f:
+    json.dump(results, f, indent=1)
+
+
+if __name__ == "__main__":
+  main()

@@ -370,3 +370,43 @@ def test_with_sample_dim_broadcasts():
 
   ensemble.WithSampleDim(Probe(), 4)(inputs, template, forcings)
   assert seen["dims"][0] == "sample" and seen["shape"][0] == 4
+
+
+# ----------------------------------------------------------------------------- device-rollout tables
+def _advance_numpy(tb, x, y, f_cur, f_next):
+  """numpy restatement of gc_advance_state (include/gcast.h), float64."""
+  f = np.concatenate([f_cur, f_next], axis=1)
+  pick = lambda a, idx: np.where(idx[None, :] >= 0, a[:, np.maximum(idx, 0)], 0.0)
+  x_next = tb["ax"] * pick(x, tb["src_x"]) + tb["ay"] * pick(y, tb["src_y"]) + pick(f, tb["src_f"])
+  pred = tb["p_ay"] * y + tb["p_ax"] * pick(x, tb["p_src_x"]) + tb["p_b"]
+  return x_next, pred
+
+
+def test_advance_tables_reproduce_the_normalised_dataset_rollout():
+  """The per-channel pick tables of rollout_device (what gc_advance_state executes) against
+  rollout.chunked_prediction(normalization.InputsAndResiduals(step)) -- 4 steps."""
+  from graphcast_amd import rollout_device
+  n_steps = 4
+  inputs, template, forcings = _example(n_steps, seed=11)
+  mean, std, dstd = synthetic.make_stats(TASK)
+  toy = _toy()
+  wrapped = normalization.InputsAndResiduals(toy, std, mean, dstd)
+  want = rollout.chunked_prediction(lambda rng, **kw: wrapped(**kw), None, inputs, template, forcings)
+
+  tb = rollout_device.build_tables(inputs, template, forcings, std, mean, dstd)
+  assert tb["c_in"] == toy.a.shape[0] and tb["c_out"] == toy.a.shape[1] and tb["n_forc"] == 5
+  stack = lambda ds: np.asarray(model_utils.dataset_to_stacked(ds, sizes=inputs.sizes).values,
+                                np.float64).reshape(-1, model_utils.dataset_to_stacked(ds, sizes=inputs.sizes).shape[-1])
+  norm = lambda ds: normalization.normalize(ds, std, mean)
+  f_rows = [stack(norm(forcings.isel(time=slice(t, t + 1)))) for t in range(n_steps)]
+  x = np.concatenate([stack(norm(inputs)), f_rows[0]], axis=1)
+  for s in range(n_steps):
+    y = np.tanh(x @ toy.a.astype(np.float64))
+    x, pred = _advance_numpy(tb, x, y, f_rows[s], f_rows[min(s + 1, n_steps - 1)])
+    got = model_utils.stacked_to_dataset(
+        xarray.Variable(("batch", "lat", "lon", "channels"),
+                        pred.reshape(1, len(LAT), len(LON), -1)), template.isel(time=slice(s, s + 1)))
+    for k in template.keys():
+      tax = want[k].dims.index("time")
+      np.testing.assert_allclose(got[k].values, np.take(want[k].values, [s], axis=tax),
+                                 rtol=2e-5, atol=2e-5, err_msg=f"{k} step {s}")

@@ -27,7 +27,7 @@ def test_header_and_binding_agree():
   assert declared_symbols() == sorted(nat.EXPORTS)
 
 
-@pytest.mark.parametrize("variant", ["glds", "regs"])
+@pytest.mark.parametrize("variant", sorted(nat.VARIANTS))
 def test_library_exports_every_declared_symbol(built, variant):
   import torch  # noqa: F401  load torch's HIP runtime first, as the product does
   lib = ctypes.CDLL(built.library_path(variant))
@@ -35,14 +35,15 @@ def test_library_exports_every_declared_symbol(built, variant):
     assert hasattr(lib, name), f"{name} missing from {variant} library"
   lib.gc_build_info.restype = ctypes.c_char_p
   info = lib.gc_build_info().decode()
-  assert "gfx950" in info and f"stage={variant}" in info
+  assert "gfx950" in info and ("pipe=1" if variant == "pipe1" else "pipe=2") in info
 
 
 def test_struct_layout_matches_header(built):
   lib = built.lib()       # lib() itself refuses to load on a mismatch
   assert lib.gc_abi_sizeof(0) == ctypes.sizeof(nat.RowMlpDesc)
   assert lib.gc_abi_sizeof(1) == ctypes.sizeof(nat.Op)
-  assert lib.gc_abi_sizeof(2) == 0
+  assert lib.gc_abi_sizeof(2) == ctypes.sizeof(nat.AdvanceDesc)
+  assert lib.gc_abi_sizeof(3) == 0
 
 
 def test_argument_validation_needs_no_gpu(built):

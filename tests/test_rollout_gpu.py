@@ -104,3 +104,32 @@ def test_normalised_rollout_resident_in_hbm(setup):
   print(f"3-step normalised rollout: worst per-variable per-step rel-RMSE {worst:.2e}")
   assert worst < 5e-5
   np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)
+
+
+def test_device_rollout_matches_dataset_rollout(setup):
+  """rollout_device.DeviceRollout (gc_advance_state fusing normalisation + residual + window
+  roll) against rollout.chunked_prediction(InputsAndResiduals(GraphCast)) on the same device
+  step: the two differ only by fp32 rounding of the normalisation algebra."""
+  from graphcast_amd import rollout_device
+  model, _ = setup
+  n_steps = 4
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, batch=2,
+                                                      num_target_steps=n_steps, seed=13)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  dut = normalization.InputsAndResiduals(model, std, mean, dstd)
+  put = lambda ds: synthetic.to_device(ds, "cuda:0")
+  want = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
+                                    device_put_fn=put)
+  roll = rollout_device.DeviceRollout(model, std, mean, dstd)
+  traj = roll.run(inputs, template, forcings)
+  assert traj.is_cuda and traj.shape[0] == n_steps
+  got = roll.to_dataset(traj, template)
+  worst = 0.0
+  for k in template.keys():
+    assert got[k].dims == want[k].dims and got[k].shape == want[k].shape
+    worst = max(worst, _rel(got[k].values, want[k].values))
+  print(f"device rollout vs dataset rollout, {n_steps} steps: worst per-variable rel diff {worst:.2e}")
+  assert worst < 2e-5
+  last = roll.run(inputs, template, forcings, keep_trajectory=False)
+  assert torch.equal(last[0], traj[-1])
+  np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)

@@ -30,18 +30,37 @@ def prec(request):
   return request.param
 
 
+class Image(np.ndarray):
+  """A packed weight image that remembers the power of two it was multiplied by."""
+  scale = 1.0
+
+
+_SCALES = {}          # device pointer of an uploaded image -> its scale (see `up` / `apply_scales`)
+
+
 def pw1(w):
   """Layer-1 weight image for the current arithmetic mode."""
   if _PREC == "f16x3":
-    return packing.pack_weight_split(w).view(np.int16)
+    sc = packing.choose_weight_scale(w)
+    img = packing.pack_weight_split(w, scale=sc).view(np.int16).view(Image)
+    img.scale = sc
+    return img
   return packing.pack_weight(w)
 
 
 def pw2(w, np_cols=D):
   """Layer-2 weight image (chained K order in split mode)."""
   if _PREC == "f16x3":
-    return packing.pack_weight_split(w, np_cols=np_cols, chained=True).view(np.int16)
+    sc = packing.choose_weight_scale(w)
+    img = packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc).view(np.int16).view(Image)
+    img.scale = sc
+    return img
   return packing.pack_weight(w, np_cols=np_cols)
+
+
+def apply_scales(d):
+  d.w1_scale = _SCALES.get(d.w1p, 1.0)
+  d.w2_scale = _SCALES.get(d.w2p, 1.0)
 
 
 def new_desc(mode, n_rows):
@@ -58,15 +77,20 @@ def dev():
 
 
 def up(a, dev, dtype=np.float32):
+  scale = getattr(a, "scale", None)
   a = np.asarray(a)
   if a.dtype == np.int16:          # split-f16 weight image: raw bits
     dtype = np.int16
-  return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).to(dev)
+  t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).to(dev)
+  if scale is not None:
+    _SCALES[t.data_ptr()] = scale
+  return t
 
 
 def run(desc):
   lib = nat.lib()
   stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  apply_scales(desc)
   nat.check(lib.gc_rowmlp(ctypes.byref(desc), stream), "gc_rowmlp")
   torch.cuda.synchronize()
 
@@ -229,6 +253,7 @@ def test_edge_block_with_segment_sum(dev, case):
   stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
   def pipeline():
+    apply_scales(d)
     nat.check(lib.gc_rowmlp(ctypes.byref(d), stream), "gc_rowmlp")
     if len(pk.fix_recv):
       f = [up(x, dev, np.int32) for x in (pk.fix_recv, pk.fix_t0, pk.fix_t1)]
