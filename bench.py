@@ -50,6 +50,21 @@ def flops_as_written(n_grid, n_mesh, e_g2m, e_mesh, e_m2g, c_in, c_out, steps, d
           + mlp(n_grid, d, c_out))
 
 
+def measured_traffic(kernel_key):
+  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+  (profiles/pmc_traffic.json, produced by scripts/pmc_summary.py from separate FETCH_SIZE /
+  WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
+  cannot run rocprofv3 on itself, so the number is attached from the profile of the SAME
+  command; null when no profile of this kernel is committed."""
+  path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+  try:
+    with open(path) as f:
+      table = json.load(f)
+  except (OSError, ValueError):
+    return None
+  return table.get(kernel_key)
+
+
 def fast_params(c_in, c_out, steps, seed=1):
   """Random-init weights of the architecture in the reference's haiku layout."""
   from graphcast_amd import params as gparams
@@ -260,7 +275,8 @@ def main():
             "mfma_issue_frac": issue * achieved / peak,
             "launches_per_step": dom["launches"],
             "avg_launch_ms": dom["ms"] / dom["launches"],
-            "traffic": None,
+            "traffic": (measured_traffic(f"{precision}:{dominant}") or {}).get("bytes_per_launch"),
+            "traffic_source": (measured_traffic(f"{precision}:{dominant}") or {}).get("source"),
             "step_executed_tflop": executed_tflop,
             "step_as_written_tflop": f_alg / 1e12,
             "step_frac_executed": executed_tflop / (ms_per_step / 1e3) / peak,

@@ -35,6 +35,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #ifndef GC_PIPE
 #define GC_PIPE 2        // split-f16 path: where the per-chunk barrier sits (see mma16_group)
 #endif
+#ifndef GC_TRACE
+#define GC_TRACE 0       // profiling ONLY: rowmlp16 writes phase timestamps of wave 0 to d.partial
+#endif                   // (launches without segment-sum; scripts/kernel_probe.py)
 #ifndef GC_EXP
 #define GC_EXP 0         // profiling experiments ONLY (scripts/kernel_probe.py; results are wrong):
 #endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA
@@ -220,7 +223,11 @@ __device__ __forceinline__ void split8(f4 a, f4 b, u4& hi, u4& lo) {
 //   2. the four hi.hi MFMAs (their fragments were requested one group ago),
 //   3. the 8 ds_read_b128 of group T+1's fragments,
 //   4. the lo.hi and hi.lo MFMAs, which cover the latency of 3.
-// Every accumulator sees its three dependent MFMAs four issue slots apart.
+// Every accumulator sees its three dependent MFMAs four issue slots apart, and NOTHING else is
+// issued between the MFMAs of a round: on this chip an instruction wedged between two
+// back-to-back MFMAs costs far more than its own issue slot (measured here: weaving the
+// swish / fp16-split VALU work of the next K step into the stream made the step slower, not
+// faster), so VALU work runs in bursts at chunk boundaries instead.
 //
 // GC_PIPE == 2 (default): the workgroup barrier that publishes the NEXT chunk sits INSIDE the
 // last group, between 2 and 3, and step 3 then requests the next chunk's first fragments: the
@@ -589,7 +596,61 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
   finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
 }
 
+#if GC_TRACE
+#define GC_MARK(k)                                                                              \
+  do {                                                                                          \
+    if (!d.seg && d.partial && threadIdx.x == 0) {                                               \
+      reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
+    }                                                                                           \
+  } while (0)
+#else
+#define GC_MARK(k) do { } while (0)
+#endif
+
 // ---- GC_PREC_F16X3 ----------------------------------------------------------------------
+// Per-lane row pointers of the layer-1 addends (nullptr = absent); pair p = n-blocks 2p, 2p+1.
+// An absent addend reads this all-zero row instead of branching: the chunk body stays one basic
+// block with a fixed instruction stream.
+__device__ float g_zero_row[kD];
+
+struct AddendRows {
+  const float* b1;
+  const float* dd;
+  const float* g0;
+  const float* g1;
+  __device__ __forceinline__ void issue(int p, f4 (&t)[8]) const {
+    const int o = 32 * p;
+    t[0] = *reinterpret_cast<const f4*>(b1 + o);
+    t[1] = *reinterpret_cast<const f4*>(b1 + o + 16);
+    t[2] = *reinterpret_cast<const f4*>(dd + o);
+    t[3] = *reinterpret_cast<const f4*>(dd + o + 16);
+    t[4] = *reinterpret_cast<const f4*>(g0 + o);
+    t[5] = *reinterpret_cast<const f4*>(g0 + o + 16);
+    t[6] = *reinterpret_cast<const f4*>(g1 + o);
+    t[7] = *reinterpret_cast<const f4*>(g1 + o + 16);
+  }
+};
+
+__device__ __forceinline__ void sum_pair(const f4 (&t)[8], f4& a, f4& b) {
+  a = (t[0] + t[2]) + (t[4] + t[6]);
+  b = (t[1] + t[3]) + (t[5] + t[7]);
+}
+
+__device__ __forceinline__ float swish1(float x);
+
+// Two pre-activation n-blocks -> the split B operand of one layer-2 K step (swish, then hi/lo
+// halves): one VALU burst per K step.
+struct SwishSplitPair {
+  f4 za, zb;
+  unsigned h[4], l[4];
+  __device__ __forceinline__ void all() {
+    split2(swish1(za.x), swish1(za.y), h[0], l[0]);
+    split2(swish1(za.z), swish1(za.w), h[1], l[1]);
+    split2(swish1(zb.x), swish1(zb.y), h[2], l[2]);
+    split2(swish1(zb.z), swish1(zb.w), h[3], l[3]);
+  }
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -598,6 +659,7 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
   constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
   constexpr int kPieces1 = 512 / 32;       // 1 KiB-per-wave DMA pieces of a layer-1 chunk
   constexpr int kPieces2 = NP2 / 32;
+  constexpr int kPairs = kNB / 2;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -614,6 +676,13 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
   const int n1 = (d.k0 + d.k1) >> 5;
   const int n1a = d.k0 >> 5;
   int q = 0;
+  GC_MARK(0);
+#if GC_TRACE
+  if (!d.seg && d.partial && threadIdx.x == 0) {
+    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 9] = __smid();
+  }
+#endif
 
   if (n1 > 0) {
     stage_chunk<512>(w1p, smem, tid);
@@ -621,8 +690,32 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
     stage_chunk<NP2>(w2p, smem, tid);
   }
 
+  // The addends b1 + d[row] + g0[idx0[row]] + g1[idx1[row]] are NOT loaded up front: a 64-row
+  // tile of them is up to 384 KiB, a phase of its own at the f16 rate.  They are streamed one
+  // n-block pair per chunk behind the MFMAs (staged in `t` one chunk, summed into `add` the next).
+  AddendRows ar;
+  ar.b1 = (d.b1 ? d.b1 : g_zero_row) + col0;
+  ar.dd = (d.d ? d.d + (size_t)rowc * d.ldd : g_zero_row) + col0;
+  ar.g0 = g_zero_row + col0;
+  ar.g1 = g_zero_row + col0;
+  if (d.g0) {
+    int ix = d.idx0[rowc];
+    ix = ix < 0 ? 0 : ix;
+    ar.g0 = d.g0 + (size_t)ix * kD + col0;
+  }
+  if (d.g1) {
+    int ix = d.idx1[rowc];
+    ix = ix < 0 ? 0 : ix;
+    ar.g1 = d.g1 + (size_t)ix * kD + col0;
+  }
+
+  // The accumulators start from the bias (in the weights' scaled space); the per-row addends are
+  // streamed behind layer 2 (below).
   f4 acc[kNB];
-  init_addends(acc, d, rowc, col0, d.w1_scale);
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) acc[nb] = d.w1_scale * *reinterpret_cast<const f4*>(ar.b1 + nb * 16);
+  ar.b1 = g_zero_row + col0;
+  f4 t0[8];               // addend staging: loads of one n-block pair in flight behind the MFMAs
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   u4 fh[4], fl[4];        // fragments of the next four n-blocks, carried across chunks
@@ -630,8 +723,11 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
     __syncthreads();      // the chunk staged in the prologue
     load_first_frags(smem, lane, fh, fl);
   }
+  GC_MARK(1);
   float* const buf0 = smem;
   float* const buf1 = smem + kBufFloats;
+  const float inv1 = 1.0f / d.w1_scale;         // exact: powers of two
+  const float inv2 = 1.0f / d.w2_scale;
 
   // ---- layer 1: the lane's 8 consecutive k of its row per chunk, split in registers ----
   if (n1 > 0) {
@@ -668,40 +764,70 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
                                        bh, bl, w2p, wave_u, lane);
     }
     ++q;
-  }
-
-  {
-    const float inv1 = 1.0f / d.w1_scale;       // exact: a power of two
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) acc[nb] *= inv1;
   }
+  GC_MARK(2);
+
   if (kLinear) {
+    if (d.d || d.g0 || d.g1) {   // per-row addends of a LINEAR launch (load-time folding only): eager
+#pragma unroll
+      for (int p = 0; p < kPairs; ++p) {
+        f4 a, b;
+        ar.issue(p, t0);
+        sum_pair(t0, a, b);
+        acc[2 * p] += a;
+        acc[2 * p + 1] += b;
+        __builtin_amdgcn_sched_barrier(0);     // (keeps the 128 loads from being hoisted together)
+      }
+    }
     store_linear(acc, d, row, col0);
     return;
   }
 
-  // ---- swish, then split the hidden layer once: blocks (2c, 2c+1) -> B operand of K step c
-  swish_all(acc);
-  u4 hh[kD / 32], hl[kD / 32];
-#pragma unroll
-  for (int cc = 0; cc < kD / 32; ++cc) split8(acc[2 * cc], acc[2 * cc + 1], hh[cc], hl[cc]);
-
+  // ---- layer 2.  K step cc consumes hidden blocks (2cc, 2cc+1) = swish(acc + addends).  The
+  // addends of pair cc+2 are requested at the top of step cc and summed at the top of step cc+1,
+  // so their latency hides behind a whole K step of MFMAs; the swish + fp16 split of pair cc+1
+  // runs as ONE VALU burst at the top of step cc (instructions wedged between back-to-back
+  // MFMAs cost far more than they hide: MI355X_MICROARCH.md, "one extra issue slot").
+  SwishSplitPair sw;
+  ar.issue(0, t0);
+  sum_pair(t0, sw.za, sw.zb);
+  ar.issue(1, t0);
+  sw.za += acc[0];
+  sw.zb += acc[1];
+  sw.all();
+  GC_MARK(3);
   f4 o2[kNB];
 #pragma unroll
   for (int nb = 0; nb < NB2; ++nb) o2[nb] = d.w2_scale * *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
 #pragma unroll
-  for (int cc = 0; cc < kD / 32; ++cc) {
-    if (cc + 1 < kD / 32) {
+  for (int cc = 0; cc < kPairs; ++cc) {
+    const u4 bh = u4{sw.h[0], sw.h[1], sw.h[2], sw.h[3]};
+    const u4 bl = u4{sw.l[0], sw.l[1], sw.l[2], sw.l[3]};
+    if (cc + 1 < kPairs) {
+      sum_pair(t0, sw.za, sw.zb);
+      sw.za += acc[2 * cc + 2];
+      sw.zb += acc[2 * cc + 3];
+      if (cc + 2 < kPairs) ar.issue(cc + 2, t0);
+      sw.all();
       mma16_chunk<NB2, kPieces2, true>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl,
-                                       hh[cc], hl[cc], w2p + (size_t)(cc + 1) * (8 * NP2 * 4),
-                                       wave_u, lane);
+                                       bh, bl, w2p + (size_t)(cc + 1) * (8 * NP2 * 4), wave_u, lane);
     } else {
-      mma16_chunk<NB2, 0, false>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl, hh[cc],
-                                 hl[cc], nullptr, wave_u, lane);
+      mma16_chunk<NB2, 0, false>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl, bh, bl,
+                                 nullptr, wave_u, lane);
     }
     ++q;
   }
+  GC_MARK(4);
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb) o2[nb] *= inv2;
   finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
+  GC_MARK(5);
+#if GC_TRACE
+  if (!d.seg && d.partial && threadIdx.x == 0)
+    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
+#endif
 }
 
 __global__ void seg_fixup_kernel(int n, const int* __restrict__ recv, const int* __restrict__ t0,
@@ -826,7 +952,7 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   gc_rowmlp_desc d = *dp;
   if (!pow2_or_unset(d.w1_scale) || !pow2_or_unset(d.w2_scale))
     return fail(GC_EINVAL, "gc_rowmlp: w1_scale / w2_scale must be powers of two");
-  if (d.w1_scale == 0.f) d.w1_scale = 1.f;
+  if (d.w1_scale == 0.f || d.k0 + d.k1 == 0) d.w1_scale = 1.f;   // (no layer-1 weights: nothing is scaled)
   if (d.w2_scale == 0.f) d.w2_scale = 1.f;
   if (d.prec == GC_PREC_F32 && (d.w1_scale != 1.f || d.w2_scale != 1.f))
     return fail(GC_EINVAL, "gc_rowmlp: weight scales are a GC_PREC_F16X3 feature");

@@ -129,6 +129,36 @@ def main():
             ("pipe2_nomfma", ["-DGC_PIPE=2", "-DGC_EXP=4"]),
             ("pipe2_nodma_noreads", ["-DGC_PIPE=2", "-DGC_EXP=3"]),
             ("pipe2_nosched", ["-DGC_PIPE=2", "-DGC_SCHED_PIN=0"])]
+  if os.environ.get("PROBE_TRACE"):
+    # phase timeline of one wave per workgroup (GC_TRACE build): cycles per phase + dispatch gaps
+    lib = build("trace", ["-DGC_PIPE=2", "-DGC_TRACE=1"])
+    out = {}
+    for name in ("gemm_only_mlp", "linear_grid", "node_grid"):
+      d, chunks, rows = shapes[name]()
+      tiles = (rows + 63) // 64
+      trace = torch.zeros((tiles, 16), dtype=torch.int64, device=dev)
+      d.partial = trace.data_ptr()
+      ms = time_launch(lib, d, iters=1)
+      t = trace.cpu().numpy()
+      ph = np.diff(t[:, :6], axis=1).astype(np.float64)
+      names = ["prologue", "layer1", "swish_split", "layer2", "finish"]
+      row = {"ms": round(ms, 4), "tiles": int(tiles), "wave_cycles_total_mean": float((t[:, 5] - t[:, 0]).mean())}
+      for j, nme in enumerate(names):
+        row[nme + "_cycles_mean"] = float(ph[:, j].mean())
+      # dispatch gap: consecutive workgroups on the same CU (smid), wall clock 100 MHz
+      gaps = []
+      for cu in np.unique(t[:, 9]):
+        sel = t[t[:, 9] == cu]
+        sel = sel[np.argsort(sel[:, 8])]
+        gaps.extend((sel[1:, 8] - sel[:-1, 10]).tolist())
+      row["wg_gap_wallclock_ticks_mean"] = float(np.mean(gaps)) if gaps else None
+      row["wg_wallclock_ticks_mean"] = float((t[:, 10] - t[:, 8]).mean())
+      row["n_cus_seen"] = int(len(np.unique(t[:, 9])))
+      out[name] = row
+      print("trace", name, json.dumps(row), flush=True)
+    with open(args.out, "w") as f:
+      json.dump(out, f, indent=1)
+    return
   only_b = os.environ.get("PROBE_BUILDS")
   only_s = os.environ.get("PROBE_SHAPES")
   if only_b:

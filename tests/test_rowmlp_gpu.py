@@ -82,8 +82,7 @@ def up(a, dev, dtype=np.float32):
   if a.dtype == np.int16:          # split-f16 weight image: raw bits
     dtype = np.int16
   t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).to(dev)
-  if scale is not None:
-    _SCALES[t.data_ptr()] = scale
+  _SCALES[t.data_ptr()] = 1.0 if scale is None else scale    # (the allocator recycles addresses)
   return t
 
 
