@@ -410,3 +410,27 @@ def test_advance_tables_reproduce_the_normalised_dataset_rollout():
       tax = want[k].dims.index("time")
       np.testing.assert_allclose(got[k].values, np.take(want[k].values, [s], axis=tax),
                                  rtol=2e-5, atol=2e-5, err_msg=f"{k} step {s}")
+
+
+def test_stacking_matches_container_free_oracle():
+  """model_utils + xarray_lite against oracle/stacking.py (plain dims/arrays restatement of
+  model_utils.py:645-776 + graphcast.py:680-723)."""
+  from oracle import stacking as ostack
+  inputs, template, forcings = synthetic.make_example(TASK, LAT, LON, batch=2, seed=4)
+  one_f = forcings.isel(time=slice(0, 1))
+  stacked = xarray.concat([model_utils.dataset_to_stacked(inputs),
+                           model_utils.dataset_to_stacked(one_f)], dim="channels")
+  got = np.asarray(model_utils.lat_lon_to_leading_axes(stacked).values)
+  got = got.reshape((-1,) + got.shape[2:])
+  plain = lambda ds: {k: (ds[k].dims, ds[k].values) for k in ds.keys()}
+  want = ostack.grid_node_features(plain(inputs), plain(one_f), inputs.sizes)
+  np.testing.assert_array_equal(got, want)
+  # and back: [N, B, C_out] -> variables
+  c_out = model_utils.dataset_to_stacked(template).sizes["channels"]
+  y = np.random.default_rng(0).standard_normal((len(LAT) * len(LON), 2, c_out)).astype(np.float32)
+  grid = xarray.DataArray(y.reshape((len(LAT), len(LON), 2, c_out)), dims=("lat", "lon", "batch", "channels"))
+  ds = model_utils.stacked_to_dataset(model_utils.restore_leading_axes(grid).variable, template)
+  ref = ostack.prediction_from_grid_nodes(y, {k: (template[k].dims, template[k].shape) for k in template.keys()},
+                                          len(LAT), len(LON))
+  for k in template.keys():
+    np.testing.assert_array_equal(ds[k].values, ref[k])
