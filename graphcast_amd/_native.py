@@ -92,7 +92,7 @@ def build(force=False, verbose=False):
     out = library_path(variant)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
       continue
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm",
            define, "-I", _INCLUDE, "-shared", "-fPIC", src, "-o", out]
     if verbose:
       print(" ".join(cmd), file=sys.stderr)

@@ -32,6 +32,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #ifndef GC_SCHED_PIN
 #define GC_SCHED_PIN 1
 #endif
+#ifndef GC_DMA_ASM
+#define GC_DMA_ASM 1     // LDS-DMA as inline asm (see stage_piece)
+#endif
 #ifndef GC_PIPE
 #define GC_PIPE 2        // split-f16 path: where the per-chunk barrier sits (see mma16_group)
 #endif
@@ -64,13 +67,36 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 
 // One 1 KiB piece (per wave) of a K chunk of packed weights -> LDS.  A chunk of NP
 // columns is 8 * NP * 4 floats = NP / 32 pieces per wave (4 waves).
+// LDS-DMA: destination = wave-uniform base (M0) + lane * 16 B (linear image), no VGPR round trip.
+//
+// GC_DMA_ASM (default): issued as inline asm.  Through the builtin, hipcc models the instruction
+// as a FLAT access that may return out of order with LDS reads, and from then on every wait for a
+// ds_read result becomes s_waitcnt lgkmcnt(0) -- which forbids keeping the NEXT group's
+// fragment reads in flight across the current group's first MFMAs.  As asm the compiler does
+// not see it at all, so the code waits for it explicitly (dma_wait) before the barrier that
+// publishes a chunk; its over-conservative vmcnt accounting for ordinary loads stays safe
+// (memory returns in order: it can only wait for more than it needs).
 __device__ __forceinline__ void stage_piece(const float* __restrict__ gsrc, float* lds, int piece,
                                             int wave, int lane) {
   const int off = piece * 1024 + wave * 256;     // wave-uniform float offset of this 1 KiB piece
-  // LDS-DMA: destination = wave-uniform base + lane * 16 B (linear image), no VGPR round trip.
+#if GC_DMA_ASM
+  const unsigned m0 = __builtin_amdgcn_readfirstlane(
+      static_cast<unsigned>(reinterpret_cast<size_t>(lds + off)));
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(m0), "v"(gsrc + off + lane * 4) : "memory", "m0");
+#else
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)(gsrc + off + lane * 4),
       (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+#endif
+}
+
+// All LDS-DMA this wave has issued has landed (a no-op for the builtin path, where the barrier's
+// own fence waits).
+__device__ __forceinline__ void dma_wait() {
+#if GC_DMA_ASM
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 // Copies one whole K chunk of packed weights (8 * NP * 4 floats, contiguous) into LDS.
@@ -258,20 +284,40 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
 #if GC_SCHED_PIN
   __builtin_amdgcn_sched_barrier(0);
 #endif
+  u4 nh[4], nl[4];
+  // With the DMA out of the compiler's sight (GC_DMA_ASM) the next group's fragments are
+  // requested BEFORE this group's MFMAs and stay in flight behind all twelve of them
+  // (s_waitcnt lgkmcnt(8) in front of the first MFMA); otherwise after the first four.
+  constexpr bool early = GC_DMA_ASM && !cross;
+  if constexpr (early) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < cnt2 && !(GC_EXP & 2)) {
+        nh[q] = wb[(n0 + 4 + q) * 128];
+        nl[q] = wb[(n0 + 4 + q) * 128 + 64];
+      } else {
+        nh[q] = ah[q];
+        nl[q] = al[q];
+      }
+    }
+#if GC_SCHED_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
 #pragma unroll
   for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
 #if GC_SCHED_PIN
   __builtin_amdgcn_sched_barrier(0);
 #endif
-  u4 nh[4], nl[4];
   if constexpr (cross) {
+    dma_wait();
     __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       nh[q] = wb_next[q * 128];
       nl[q] = wb_next[q * 128 + 64];
     }
-  } else {
+  } else if constexpr (!early) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (q < cnt2 && !(GC_EXP & 2)) {
@@ -325,6 +371,7 @@ __device__ __forceinline__ void mma16_chunk(f4 (&acc)[kNB], const float* wbuf, f
   const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
   const u4* wbn = reinterpret_cast<const u4*>(wnext) + lane;
   if (GC_PIPE == 1) {
+    dma_wait();
     __syncthreads();      // this chunk landed; the previous chunk's readers are done
     load_first_frags(wbuf, lane, fh, fl);
   }
@@ -541,6 +588,7 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
     bn1 = bc1;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     for (int c = 0; c + 1 < n1; ++c) {
+      dma_wait();
       __syncthreads();   // chunk c landed in LDS; previous chunk's readers are done
       {
         const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
@@ -554,6 +602,7 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
       bc1 = bn1;
       ++q;
     }
+    dma_wait();
     __syncthreads();     // last layer-1 chunk; the first layer-2 chunk streams in behind it
     if (kLinear) {
       mma_chunk<kNB, 512, 0>(acc, smem + (q & 1) * kBufFloats, bc0, bc1, i, g, nullptr, nullptr,
@@ -581,6 +630,7 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
     for (int cc = 0; cc < kD / 32; ++cc) {
+      dma_wait();
       __syncthreads();
       if (cc + 1 < kD / 32) {
         mma_chunk<NB2, NP2, NP2>(o2, smem + (q & 1) * kBufFloats, acc[2 * cc], acc[2 * cc + 1], i, g,
@@ -720,6 +770,7 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
 
   u4 fh[4], fl[4];        // fragments of the next four n-blocks, carried across chunks
   if (GC_PIPE == 2) {
+    dma_wait();
     __syncthreads();      // the chunk staged in the prologue
     load_first_frags(smem, lane, fh, fl);
   }

@@ -183,6 +183,8 @@ class DeviceRollout:
     # forcings of every target time, normalised, uploaded once (20 MB per 0.25 deg step)
     f_rows = [self._normalised_forcing_rows(forcings, t) for t in range(n_steps)]
     stream = lambda: ctypes.c_void_p(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     for s in range(n_steps):
       model.forward_grid_node_features(x, y)
       d = nat.AdvanceDesc()
@@ -195,8 +197,16 @@ class DeviceRollout:
       d.pred = traj[s if keep_trajectory else 0].data_ptr()
       nat.check(self._lib.gc_advance_state(ctypes.byref(d), stream()), "gc_advance_state")
       x, x_next = x_next, x
+    ev1.record()
     self.final_state = x
+    self._loop_events = (ev0, ev1)
     return traj
+
+  def last_loop_ms(self) -> float:
+    """Device time of the last run()'s step loop (steps + state advances), milliseconds."""
+    ev0, ev1 = self._loop_events
+    ev1.synchronize()
+    return ev0.elapsed_time(ev1)
 
   def to_dataset(self, traj: torch.Tensor, targets_template: xarray.Dataset, host: bool = True):
     """Trajectory tensor -> Dataset shaped like ``targets_template`` (reference

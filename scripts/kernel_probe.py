@@ -25,7 +25,7 @@ D = 512
 
 def build(tag, defines):
   out = f"/tmp/libgcast_{tag}.so"
-  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", *defines,
+  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm", *defines,
          "-I", os.path.join(ROOT, "include"), "-shared", "-fPIC",
          os.path.join(ROOT, "graphcast_amd", "csrc", "gcast.hip"), "-o", out]
   subprocess.run(cmd, check=True)
@@ -123,7 +123,8 @@ def main():
     return d, 48, n_g
 
   shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, linear_grid=linear_grid, node_grid=node_grid)
-  builds = [("pipe2", ["-DGC_PIPE=2"]), ("pipe1", ["-DGC_PIPE=1"]),
+  builds = [("pipe2", ["-DGC_PIPE=2"]), ("pipe2_dma_builtin", ["-DGC_PIPE=2", "-DGC_DMA_ASM=0"]),
+            ("pipe1", ["-DGC_PIPE=1"]),
             ("pipe2_nodma", ["-DGC_PIPE=2", "-DGC_EXP=1"]),
             ("pipe2_noreads", ["-DGC_PIPE=2", "-DGC_EXP=2"]),
             ("pipe2_nomfma", ["-DGC_PIPE=2", "-DGC_EXP=4"]),
