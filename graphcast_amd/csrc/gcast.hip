@@ -218,17 +218,19 @@ __device__ __forceinline__ f4 mfma32h(u4 a, u4 b, f4 c) {
                                                 c, 0, 0, 0);
 }
 
-constexpr float kHalfMax = 65504.0f;
+// (a, b) -> packed halves hi, lo with hi + lo = the input to 20+ bits.  Both conversions round
+// toward zero (v_cvt_pkrtz_f16_f32: two values per instruction): hi is the input truncated to 11
+// bits, the remainder a - hi is exact in fp32 and has the input's sign, lo is the remainder
+// truncated to 11 bits => |a - (hi + lo)| < 2^-20 |a|.  Round-toward-zero also SATURATES
+// instead of overflowing to inf: beyond +-65504 hi clamps and lo carries the excess (exact up
+// to 1.3e5), no clamps needed.
+typedef __fp16 p2 __attribute__((ext_vector_type(2)));
 
-// (a, b) -> packed halves hi, lo.  Saturating: beyond +-65504 hi clamps and lo carries the
-// excess (exact up to 1.3e5), instead of producing inf.
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  const float ca = __builtin_amdgcn_fmed3f(a, -kHalfMax, kHalfMax);
-  const float cb = __builtin_amdgcn_fmed3f(b, -kHalfMax, kHalfMax);
-  const h2 h = {static_cast<_Float16>(ca), static_cast<_Float16>(cb)};
-  const float ra = __builtin_amdgcn_fmed3f(a - static_cast<float>(h.x), -kHalfMax, kHalfMax);
-  const float rb = __builtin_amdgcn_fmed3f(b - static_cast<float>(h.y), -kHalfMax, kHalfMax);
-  const h2 l = {static_cast<_Float16>(ra), static_cast<_Float16>(rb)};
+  const p2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  const float ra = a - static_cast<float>(h.x);
+  const float rb = b - static_cast<float>(h.y);
+  const p2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
@@ -300,6 +302,17 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
         nl[q] = al[q];
       }
     }
+    // one explicit wait for everything OLDER than the reads just issued (this group's fragments,
+    // requested 12 MFMAs ago): the compiler then has nothing left to wait for between the MFMAs
+    // (it would otherwise drip s_waitcnt lgkmcnt(14..8) in between them)
+    constexpr int kInFlight = 2 * cnt2;
+    __builtin_amdgcn_s_waitcnt(0xC07F | (kInFlight << 8));    // vmcnt(63) expcnt(7) lgkmcnt(kInFlight)
+#if GC_SCHED_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+  if constexpr (GC_DMA_ASM && !early) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this group's fragments, in one wait
 #if GC_SCHED_PIN
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -664,26 +677,23 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
 __device__ float g_zero_row[kD];
 
 struct AddendRows {
-  const float* b1;
   const float* dd;
   const float* g0;
   const float* g1;
-  __device__ __forceinline__ void issue(int p, f4 (&t)[8]) const {
+  __device__ __forceinline__ void issue(int p, f4 (&t)[6]) const {
     const int o = 32 * p;
-    t[0] = *reinterpret_cast<const f4*>(b1 + o);
-    t[1] = *reinterpret_cast<const f4*>(b1 + o + 16);
-    t[2] = *reinterpret_cast<const f4*>(dd + o);
-    t[3] = *reinterpret_cast<const f4*>(dd + o + 16);
-    t[4] = *reinterpret_cast<const f4*>(g0 + o);
-    t[5] = *reinterpret_cast<const f4*>(g0 + o + 16);
-    t[6] = *reinterpret_cast<const f4*>(g1 + o);
-    t[7] = *reinterpret_cast<const f4*>(g1 + o + 16);
+    t[0] = *reinterpret_cast<const f4*>(dd + o);
+    t[1] = *reinterpret_cast<const f4*>(dd + o + 16);
+    t[2] = *reinterpret_cast<const f4*>(g0 + o);
+    t[3] = *reinterpret_cast<const f4*>(g0 + o + 16);
+    t[4] = *reinterpret_cast<const f4*>(g1 + o);
+    t[5] = *reinterpret_cast<const f4*>(g1 + o + 16);
   }
 };
 
-__device__ __forceinline__ void sum_pair(const f4 (&t)[8], f4& a, f4& b) {
-  a = (t[0] + t[2]) + (t[4] + t[6]);
-  b = (t[1] + t[3]) + (t[5] + t[7]);
+__device__ __forceinline__ void sum_pair(const f4 (&t)[6], f4& a, f4& b) {
+  a = t[0] + (t[2] + t[4]);
+  b = t[1] + (t[3] + t[5]);
 }
 
 __device__ __forceinline__ float swish1(float x);
@@ -743,8 +753,8 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
   // The addends b1 + d[row] + g0[idx0[row]] + g1[idx1[row]] are NOT loaded up front: a 64-row
   // tile of them is up to 384 KiB, a phase of its own at the f16 rate.  They are streamed one
   // n-block pair per chunk behind the MFMAs (staged in `t` one chunk, summed into `add` the next).
+  const float* b1row = (d.b1 ? d.b1 : g_zero_row) + col0;
   AddendRows ar;
-  ar.b1 = (d.b1 ? d.b1 : g_zero_row) + col0;
   ar.dd = (d.d ? d.d + (size_t)rowc * d.ldd : g_zero_row) + col0;
   ar.g0 = g_zero_row + col0;
   ar.g1 = g_zero_row + col0;
@@ -763,9 +773,8 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
   // streamed behind layer 2 (below).
   f4 acc[kNB];
 #pragma unroll
-  for (int nb = 0; nb < kNB; ++nb) acc[nb] = d.w1_scale * *reinterpret_cast<const f4*>(ar.b1 + nb * 16);
-  ar.b1 = g_zero_row + col0;
-  f4 t0[8];               // addend staging: loads of one n-block pair in flight behind the MFMAs
+  for (int nb = 0; nb < kNB; ++nb) acc[nb] = d.w1_scale * *reinterpret_cast<const f4*>(b1row + nb * 16);
+  f4 t0[6];               // addend staging: loads of one n-block pair in flight behind the MFMAs
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   u4 fh[4], fl[4];        // fragments of the next four n-blocks, carried across chunks

@@ -1,0 +1,188 @@
+"""Spatial partition of the three GraphCast graphs across GPUs (BASELINE.json config 5).
+
+Nodes (grid nodes and mesh nodes) are split into P parts by longitude band; every edge belongs
+to the **owner of its receiver**, so the receiver aggregation (``jraph.segment_sum``,
+``typed_graph_net.py:532-538``) is local to a rank -- the "shard-local => drop the collective"
+case of the reference's own sharded ops (``gather_scatter_ops.py:102-144``).  What a rank needs
+from others are *sender* rows only:
+
+  encoder   : ``(h_grid . W_s)`` rows of grid nodes that send into its mesh nodes     (1 exchange)
+  processor : ``(h_mesh . W_s)`` rows of remote mesh senders, every message-passing step (16)
+  decoder   : ``(h_mesh . W_s)`` rows of remote mesh senders of its grid nodes          (1)
+
+i.e. 18 halo exchanges per 6-h step of 512-float rows (SURVEY.md 8e measured ~0.9 MB per rank
+per processor step at 0.25 deg / 8 parts: latency-bound, so each exchange is ONE
+``all_to_all_single`` with precomputed split sizes).
+
+Local index space of a rank, per node set: ``[owned nodes (global order) | halo nodes (grouped by
+owner rank, global order within a group)]``.  Kernels run over the owned prefix; an exchange
+fills the halo suffix.  This module is pure numpy (plan) + a small exchanger over
+``torch.distributed`` (nccl = RCCL on GPUs, gloo on CPU in the tests) or, for single-process
+emulation of P ranks on one GPU, plain tensor copies.
+"""
+from typing import Dict, List, NamedTuple, Sequence
+
+import numpy as np
+
+
+class NodeSetPartition(NamedTuple):
+  owner: np.ndarray              # [N] rank owning each global node
+  owned: List[np.ndarray]        # per rank: global ids it owns (ascending)
+  local_of_global: List[Dict]    # (filled lazily) not used on the hot path
+
+
+class HaloPlan(NamedTuple):
+  """Remote sender rows of one edge set for one rank."""
+  halo_global: np.ndarray        # [H] global ids of the halo nodes, grouped by owner rank
+  recv_counts: np.ndarray        # [P] rows received from each rank (sum = H)
+  send_local: List[np.ndarray]   # per destination rank: LOCAL owned indices to send (ascending global)
+
+
+class RankGraphs(NamedTuple):
+  """What one rank builds its engine from: local graphs + exchange plans."""
+  rank: int
+  graphs: dict                   # same layout as GraphCast.graph_arrays(), in local indices
+  grid_owned: np.ndarray         # global grid ids owned (ascending) -> rows of x / y it handles
+  mesh_owned: np.ndarray
+  n_grid_owned: int
+  n_mesh_owned: int
+  halo_g2m: HaloPlan             # grid rows needed by the encoder
+  halo_mesh: HaloPlan            # mesh rows needed by every processor step
+  halo_m2g: HaloPlan             # mesh rows needed by the decoder
+
+
+def owner_by_longitude(lon_deg: np.ndarray, n_parts: int) -> np.ndarray:
+  """Equal-count longitude bands (ties broken by index): rank of each node."""
+  lon = np.mod(np.asarray(lon_deg, dtype=np.float64), 360.0)
+  order = np.lexsort((np.arange(len(lon)), lon))
+  owner = np.empty(len(lon), dtype=np.int32)
+  bounds = np.linspace(0, len(lon), n_parts + 1).astype(np.int64)
+  for p in range(n_parts):
+    owner[order[bounds[p]:bounds[p + 1]]] = p
+  return owner
+
+
+def _halo(senders, receivers, send_owner, recv_owner, owned_senders: Sequence[np.ndarray], rank, n_parts):
+  """Remote senders of the edges whose receiver `rank` owns."""
+  mine = recv_owner[receivers] == rank
+  snd = np.unique(senders[mine])
+  remote = snd[send_owner[snd] != rank]
+  groups = [remote[send_owner[remote] == q] for q in range(n_parts)]      # ascending within a group
+  halo_global = np.concatenate(groups) if len(remote) else np.zeros(0, dtype=np.int64)
+  return halo_global.astype(np.int64), np.array([len(g) for g in groups], dtype=np.int64)
+
+
+def plan(graphs: dict, grid_lon: np.ndarray, mesh_lon: np.ndarray, n_parts: int) -> List[RankGraphs]:
+  """Splits ``GraphCast.graph_arrays()`` into per-rank local graphs + halo plans.
+
+  ``grid_lon`` / ``mesh_lon``: longitude (degrees) of every grid / mesh node."""
+  n_grid, n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
+  g_owner = owner_by_longitude(grid_lon, n_parts)
+  m_owner = owner_by_longitude(mesh_lon, n_parts)
+  g_owned = [np.flatnonzero(g_owner == p) for p in range(n_parts)]
+  m_owned = [np.flatnonzero(m_owner == p) for p in range(n_parts)]
+  g2m, mesh, m2g = graphs["g2m"], graphs["mesh"], graphs["m2g"]
+  as64 = lambda a: np.asarray(a).astype(np.int64)
+  es = dict(g2m=(as64(g2m["senders"]), as64(g2m["receivers"]), g_owner, m_owner),
+            mesh=(as64(mesh["senders"]), as64(mesh["receivers"]), m_owner, m_owner),
+            m2g=(as64(m2g["senders"]), as64(m2g["receivers"]), m_owner, g_owner))
+  halos = {k: [_halo(s, r, so, ro, None, p, n_parts) for p in range(n_parts)]
+           for k, (s, r, so, ro) in es.items()}
+
+  def local_map(owned, halo_global, n):
+    m = np.full(n, -1, dtype=np.int64)
+    m[owned] = np.arange(len(owned))
+    m[halo_global] = len(owned) + np.arange(len(halo_global))
+    return m
+
+  def send_lists(key, owned_by_rank, src_rank):
+    """For source rank `src_rank`: local owned indices to send to every destination."""
+    out = []
+    pos = np.full(max(n_grid, n_mesh), -1, dtype=np.int64)
+    pos[owned_by_rank[src_rank]] = np.arange(len(owned_by_rank[src_rank]))
+    for dst in range(n_parts):
+      hg, counts = halos[key][dst]
+      start = int(counts[:src_rank].sum())
+      ids = hg[start:start + int(counts[src_rank])]
+      out.append(pos[ids])
+    return out
+
+  ranks = []
+  for p in range(n_parts):
+    # node index spaces differ per edge set (the halo of the encoder's grid senders is not the
+    # halo of anything else): each edge set gets its own sender-side local map
+    def edge_set(key, feat, n_send, n_recv, send_owned, recv_owned):
+      s, r, so, ro = es[key]
+      mine = ro[r] == p
+      hg, _ = halos[key][p]
+      smap = local_map(send_owned[p], hg, n_send)
+      rmap = np.full(n_recv, -1, dtype=np.int64)
+      rmap[recv_owned[p]] = np.arange(len(recv_owned[p]))
+      ls, lr = smap[s[mine]], rmap[r[mine]]
+      assert (ls >= 0).all() and (lr >= 0).all()
+      return dict(senders=ls, receivers=lr, feat=np.asarray(feat)[mine], edge_ids=np.flatnonzero(mine))
+
+    local = dict(
+        n_grid=len(g_owned[p]), n_mesh=len(m_owned[p]), radius=graphs.get("radius"),
+        n_grid_senders=len(g_owned[p]) + len(halos["g2m"][p][0]),
+        n_mesh_senders=len(m_owned[p]) + len(halos["mesh"][p][0]),
+        n_mesh_senders_dec=len(m_owned[p]) + len(halos["m2g"][p][0]),
+        grid_node_feat=np.asarray(graphs["grid_node_feat"])[g_owned[p]],
+        mesh_node_feat=np.asarray(graphs["mesh_node_feat"])[m_owned[p]],
+        g2m=edge_set("g2m", g2m["feat"], n_grid, n_mesh, g_owned, m_owned),
+        mesh=edge_set("mesh", mesh["feat"], n_mesh, n_mesh, m_owned, m_owned),
+        m2g=edge_set("m2g", m2g["feat"], n_mesh, n_grid, m_owned, g_owned))
+    mk = lambda key, owned_by_rank: HaloPlan(halos[key][p][0], halos[key][p][1],
+                                             send_lists(key, owned_by_rank, p))
+    ranks.append(RankGraphs(
+        rank=p, graphs=local, grid_owned=g_owned[p], mesh_owned=m_owned[p],
+        n_grid_owned=len(g_owned[p]), n_mesh_owned=len(m_owned[p]),
+        halo_g2m=mk("g2m", g_owned), halo_mesh=mk("mesh", m_owned), halo_m2g=mk("m2g", m_owned)))
+  return ranks
+
+
+# ----------------------------------------------------------------------------- exchangers
+class LocalExchanger:
+  """All P ranks live in this process (emulation on one GPU / CPU): halo rows are copied
+  directly between the ranks' tensors.  ``tensors[q]`` is rank q's row table
+  ``[owned_q + halo_q, 512]``; the owned prefix is valid on entry, the halo suffix on exit."""
+
+  def __init__(self, plans: Sequence[HaloPlan], n_owned: Sequence[int]):
+    self.plans, self.n_owned = list(plans), list(n_owned)
+
+  def exchange(self, tensors):
+    import torch
+    n_parts = len(self.plans)
+    for dst in range(n_parts):
+      offset = self.n_owned[dst]
+      for src in range(n_parts):
+        idx = self.plans[src].send_local[dst]
+        if len(idx) == 0:
+          continue
+        rows = tensors[src][torch.as_tensor(idx, device=tensors[src].device)]
+        tensors[dst][offset:offset + len(idx)] = rows.to(tensors[dst].device)
+        offset += len(idx)
+
+
+class DistExchanger:
+  """One rank per process: ONE ``all_to_all_single`` per exchange (nccl = RCCL over xGMI on GPUs,
+  gloo on CPU).  Send rows are packed by one index_select, received rows land directly in the
+  contiguous halo suffix of the table."""
+
+  def __init__(self, plan_: HaloPlan, n_owned: int, device, group=None):
+    import torch
+    self.n_owned, self.group = n_owned, group
+    self.send_counts = [int(len(i)) for i in plan_.send_local]
+    self.recv_counts = [int(c) for c in plan_.recv_counts]
+    idx = np.concatenate([np.asarray(i, dtype=np.int64) for i in plan_.send_local]) \
+        if sum(self.send_counts) else np.zeros(0, dtype=np.int64)
+    self.send_index = torch.as_tensor(idx, device=device)
+
+  def exchange(self, table):
+    import torch
+    import torch.distributed as dist
+    send = table.index_select(0, self.send_index) if self.send_index.numel() else table[:0]
+    recv = table[self.n_owned:self.n_owned + sum(self.recv_counts)]
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=self.recv_counts,
+                           input_split_sizes=self.send_counts, group=self.group)
+    return table
