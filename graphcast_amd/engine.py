@@ -124,6 +124,12 @@ class StepEngine:
     self.precision = precision
     self.prec = nat.PRECISIONS[precision]
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
+    # Spatially partitioned graphs (partition.plan): node tables that edges GATHER from carry a
+    # halo suffix of remote sender rows behind the owned rows; kernels run over the owned prefix
+    # and a halo exchange (see `segments`) fills the suffix.  Unpartitioned: no suffix.
+    self.ng_tab = int(graphs.get("n_grid_senders", self.n_grid))
+    self.nm_tab = max(int(graphs.get("n_mesh_senders", self.n_mesh)),
+                      int(graphs.get("n_mesh_senders_dec", self.n_mesh)))
     self.c_in, self.c_out, self.num_steps = c_in, c_out, num_steps
     self.n_struct = graphs["grid_node_feat"].shape[1]
     self.kp = packing.round_up(c_in + self.n_struct, packing.K_CHUNK)
@@ -133,6 +139,7 @@ class StepEngine:
     self._keep = []            # keeps every tensor referenced by raw pointer alive
     self._build(graphs, params)
     self._programs: Dict[int, tuple] = {}
+    self._cuts: Dict[int, list] = {}
 
   # ---------------------------------------------------------------- helpers
   def _new(self, rows, cols=D):
@@ -286,12 +293,12 @@ class StepEngine:
     # ---- per-step workspace ---------------------------------------------------
     self.xin = self._new(ng, self.kp)
     self.h_grid = self._new(ng)         # embedded grid latents, later reused for the decoder update
-    self.pre_grid = self._new(ng)       # h_grid.Ws (encoder) / h_grid2.Wr (decoder)
+    self.pre_grid = self._new(self.ng_tab)   # h_grid.Ws (encoder; + halo rows) / h_grid2.Wr (decoder)
     self.h_grid2 = self._new(ng)        # grid latents after the encoder's node update
     self.agg_grid = self._new(ng)
     self.h_mesh = self._new(nm)
     self.agg_mesh = self._new(nm)
-    self.pre_s_mesh = self._new(nm)
+    self.pre_s_mesh = self._new(self.nm_tab)   # h_mesh.Ws (+ halo rows of remote senders)
     self.pre_r_mesh = self._new(nm)
     self.e_mesh_lat = self._new(self.e_mesh.n_rows)
 
@@ -302,6 +309,7 @@ class StepEngine:
       return self._programs[batch]
     ng, nm = self.n_grid, self.n_mesh
     ops, x_slots, y_slots = [], [], []
+    cuts = []          # (index of the first op AFTER a halo exchange point, which table)
     for b in range(batch):
       op = nat.Op()
       op.kind, op.tag, op.n = nat.OP_PREP, TAGS["prep"], ng
@@ -316,6 +324,7 @@ class StepEngine:
       m = self.m_g2m_edge
       ops.append(self._op_mlp("enc_pre", self._desc(
           nat.MODE_LINEAR, ng, a0=self.h_grid, k0=D, w1p=m.w1["s"], out=self.pre_grid)))
+      cuts.append((len(ops), "g2m"))
       ops.append(self._op_mlp("enc_edge", self._mlp_ln(
           self.e_g2m.n_rows, m, d=self.d_g2m, g0=self.pre_grid, idx0=self.e_g2m.snd,
           edges=self.e_g2m, agg=self.agg_mesh)))
@@ -335,6 +344,7 @@ class StepEngine:
             nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=me.w1["s"], out=self.pre_s_mesh)))
         ops.append(self._op_mlp("proc_pre", self._desc(
             nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=me.w1["r"], out=self.pre_r_mesh)))
+        cuts.append((len(ops), "mesh"))
         common = dict(g0=self.pre_s_mesh, idx0=self.e_mesh.snd, g1=self.pre_r_mesh,
                       idx1=self.e_mesh.rcv, edges=self.e_mesh, agg=self.agg_mesh)
         if i == 0:
@@ -357,6 +367,7 @@ class StepEngine:
           nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=m.w1["s"], out=self.pre_s_mesh)))
       ops.append(self._op_mlp("dec_pre", self._desc(
           nat.MODE_LINEAR, ng, a0=self.h_grid2, k0=D, w1p=m.w1["r"], out=self.pre_grid)))
+      cuts.append((len(ops), "m2g"))
       ops.append(self._op_mlp("dec_edge", self._mlp_ln(
           self.e_m2g.n_rows, m, d=self.d_m2g, g0=self.pre_s_mesh, idx0=self.e_m2g.snd,
           g1=self.pre_grid, idx1=self.e_m2g.rcv, edges=self.e_m2g, agg=self.agg_grid)))
@@ -372,6 +383,7 @@ class StepEngine:
           n2=self.c_out, out_ptr=0, ldo=batch * self.c_out)))
     arr = (nat.Op * len(ops))(*ops)
     self._programs[batch] = (arr, x_slots, y_slots)
+    self._cuts[batch] = cuts
     return self._programs[batch]
 
   def bind(self, x: torch.Tensor, y: Optional[torch.Tensor] = None):
@@ -398,6 +410,36 @@ class StepEngine:
     return y
 
   __call__ = forward
+
+  # ---------------------------------------------------------------- partitioned execution
+  def segments(self, x: torch.Tensor, y: Optional[torch.Tensor] = None):
+    """The step as launch segments separated by halo exchange points (partition.py).
+
+    Returns ``(y, [(run, table_name), ...])``: call ``run()`` (enqueues the segment's launches on
+    the current stream), then exchange the halo suffix of ``self.halo_table(table_name)`` with
+    the other ranks (``table_name`` is None after the last segment).  18 exchange points per
+    batch element: 1 encoder, 1 per processor step, 1 decoder."""
+    arr, y = self.bind(x, y)
+    cuts = self._cuts[x.shape[1]]
+    bounds = [0] + [c for c, _ in cuts] + [len(arr)]
+    names = [n for _, n in cuts] + [None]
+    segs = []
+    for k in range(len(bounds) - 1):
+      lo, hi = bounds[k], bounds[k + 1]
+      sub = ctypes.cast(ctypes.byref(arr, lo * ctypes.sizeof(nat.Op)), ctypes.POINTER(nat.Op))
+
+      def run(sub=sub, n=hi - lo):
+        nat.check(self.lib.gc_run_program(sub, n, self._stream_ptr()), "gc_run_program")
+      segs.append((run, names[k]))
+    self._bound = arr            # keeps the op array alive while the closures are in use
+    return y, segs
+
+  def halo_table(self, name: str) -> torch.Tensor:
+    """The row table whose halo suffix the exchange `name` fills (owned prefix already valid)."""
+    return self.pre_grid if name == "g2m" else self.pre_s_mesh
+
+  def owned_rows(self, name: str) -> int:
+    return self.n_grid if name == "g2m" else self.n_mesh
 
   def time_ops(self, x, iters=3):
     """Per-op mean milliseconds measured with HIP events on the launch stream."""

@@ -20,15 +20,9 @@ fills the halo suffix.  This module is pure numpy (plan) + a small exchanger ove
 ``torch.distributed`` (nccl = RCCL on GPUs, gloo on CPU in the tests) or, for single-process
 emulation of P ranks on one GPU, plain tensor copies.
 """
-from typing import Dict, List, NamedTuple, Sequence
+from typing import List, NamedTuple, Sequence
 
 import numpy as np
-
-
-class NodeSetPartition(NamedTuple):
-  owner: np.ndarray              # [N] rank owning each global node
-  owned: List[np.ndarray]        # per rank: global ids it owns (ascending)
-  local_of_global: List[Dict]    # (filled lazily) not used on the hot path
 
 
 class HaloPlan(NamedTuple):
@@ -62,7 +56,7 @@ def owner_by_longitude(lon_deg: np.ndarray, n_parts: int) -> np.ndarray:
   return owner
 
 
-def _halo(senders, receivers, send_owner, recv_owner, owned_senders: Sequence[np.ndarray], rank, n_parts):
+def _halo(senders, receivers, send_owner, recv_owner, rank, n_parts):
   """Remote senders of the edges whose receiver `rank` owns."""
   mine = recv_owner[receivers] == rank
   snd = np.unique(senders[mine])
@@ -86,7 +80,7 @@ def plan(graphs: dict, grid_lon: np.ndarray, mesh_lon: np.ndarray, n_parts: int)
   es = dict(g2m=(as64(g2m["senders"]), as64(g2m["receivers"]), g_owner, m_owner),
             mesh=(as64(mesh["senders"]), as64(mesh["receivers"]), m_owner, m_owner),
             m2g=(as64(m2g["senders"]), as64(m2g["receivers"]), m_owner, g_owner))
-  halos = {k: [_halo(s, r, so, ro, None, p, n_parts) for p in range(n_parts)]
+  halos = {k: [_halo(s, r, so, ro, p, n_parts) for p in range(n_parts)]
            for k, (s, r, so, ro) in es.items()}
 
   def local_map(owned, halo_global, n):
@@ -186,3 +180,77 @@ class DistExchanger:
     dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=self.recv_counts,
                            input_split_sizes=self.send_counts, group=self.group)
     return table
+
+
+# ----------------------------------------------------------------------------- runners
+def tables_of(rank_graphs: RankGraphs):
+  """Exchange name -> (halo plan, owned rows) of one rank."""
+  return {"g2m": (rank_graphs.halo_g2m, rank_graphs.n_grid_owned),
+          "mesh": (rank_graphs.halo_mesh, rank_graphs.n_mesh_owned),
+          "m2g": (rank_graphs.halo_m2g, rank_graphs.n_mesh_owned)}
+
+
+class EmulatedPartitionedStep:
+  """All P ranks of a partitioned step in ONE process on ONE device: P engines over the local
+  graphs run their launch segments in lockstep and halo rows are copied between their tables.
+  Numerically this is the multi-GPU execution (same kernels, same local graphs, same exchange
+  points); it exists to validate config 5 on a single MI355X and in CI."""
+
+  def __init__(self, graphs: dict, params, grid_lon, mesh_lon, n_parts: int, *, num_steps: int,
+               c_in: int, c_out: int, device="cuda:0", precision=None):
+    from graphcast_amd import engine
+    self.ranks = plan(graphs, grid_lon, mesh_lon, n_parts)
+    self.engines = [engine.StepEngine(r.graphs, params, num_steps=num_steps, c_in=c_in, c_out=c_out,
+                                      device=device, precision=precision) for r in self.ranks]
+    self.exchangers = {
+        name: LocalExchanger([tables_of(r)[name][0] for r in self.ranks],
+                             [tables_of(r)[name][1] for r in self.ranks])
+        for name in ("g2m", "mesh", "m2g")}
+    self.n_grid = int(graphs["n_grid"])
+    self.c_out = c_out
+    self.exchanges_per_call = 0
+
+  def forward(self, x):
+    import torch
+    xs = [x[torch.as_tensor(r.grid_owned, device=x.device)].contiguous() for r in self.ranks]
+    bound = [e.segments(xl) for e, xl in zip(self.engines, xs)]
+    n_seg = len(bound[0][1])
+    self.exchanges_per_call = 0
+    for k in range(n_seg):
+      for _, segs in bound:
+        segs[k][0]()
+      name = bound[0][1][k][1]
+      if name is not None:
+        self.exchangers[name].exchange([e.halo_table(name) for e in self.engines])
+        self.exchanges_per_call += 1
+    y = torch.empty((self.n_grid, x.shape[1], self.c_out), dtype=torch.float32, device=x.device)
+    for r, (yl, _) in zip(self.ranks, bound):
+      y[torch.as_tensor(r.grid_owned, device=x.device)] = yl
+    return y
+
+  __call__ = forward
+
+
+class DistributedPartitionedStep:
+  """One rank of a partitioned step, one process per GPU: the local engine's segments
+  interleaved with ONE all_to_all_single per halo exchange (RCCL over xGMI)."""
+
+  def __init__(self, rank_graphs: RankGraphs, params, *, num_steps: int, c_in: int, c_out: int,
+               device, precision=None, group=None):
+    from graphcast_amd import engine
+    self.rank_graphs = rank_graphs
+    self.engine = engine.StepEngine(rank_graphs.graphs, params, num_steps=num_steps, c_in=c_in,
+                                    c_out=c_out, device=device, precision=precision)
+    self.exchangers = {name: DistExchanger(pl, n_owned, device, group)
+                       for name, (pl, n_owned) in tables_of(rank_graphs).items()}
+
+  def forward(self, x_local, y_local=None):
+    """x_local = rows ``rank_graphs.grid_owned`` of the global [N_grid, B, C_in] input."""
+    y, segs = self.engine.segments(x_local, y_local)
+    for run, name in segs:
+      run()
+      if name is not None:
+        self.exchangers[name].exchange(self.engine.halo_table(name))
+    return y
+
+  __call__ = forward

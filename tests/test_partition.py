@@ -1,0 +1,94 @@
+"""CPU tests of the spatial partition plan (BASELINE.json config 5): receiver-owned edges,
+local index spaces [owned | halo], halo exchange plans -- and of both exchangers (in-process
+copies; torch.distributed all_to_all_single over gloo, world_size 2)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from graphcast_amd import partition                     # noqa: E402
+from oracle import graphcast as ogc                     # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RES, MESH = 6.0, 2
+
+
+@pytest.fixture(scope="module")
+def graphs():
+  lat = np.arange(-90, 90 + RES / 2, RES)
+  lon = np.arange(0, 360, RES)
+  g = ogc.build_graphs(lat, lon, MESH)
+  glon = np.meshgrid(lon, lat)[0].reshape(-1)
+  return g, glon, np.asarray(g["mesh_lon"])
+
+
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8])
+def test_plan_invariants(graphs, n_parts):
+  g, glon, mlon = graphs
+  ranks = partition.plan(g, glon, mlon, n_parts)
+  assert sorted(np.concatenate([r.grid_owned for r in ranks]).tolist()) == list(range(g["n_grid"]))
+  assert sorted(np.concatenate([r.mesh_owned for r in ranks]).tolist()) == list(range(g["n_mesh"]))
+  sizes = [r.n_grid_owned for r in ranks]
+  assert max(sizes) - min(sizes) <= 1                         # equal-count bands
+  for key, n_edges in (("g2m", len(g["g2m"]["senders"])), ("mesh", len(g["mesh"]["senders"])),
+                       ("m2g", len(g["m2g"]["senders"]))):
+    ids = np.concatenate([r.graphs[key]["edge_ids"] for r in ranks])
+    assert sorted(ids.tolist()) == list(range(n_edges))       # every edge on exactly one rank
+    for r in ranks:
+      e = r.graphs[key]
+      n_recv = r.n_mesh_owned if key != "m2g" else r.n_grid_owned
+      assert e["receivers"].min() >= 0 and e["receivers"].max() < n_recv      # receivers are owned
+      assert np.all(np.diff(e["edge_ids"]) > 0)               # original relative order kept
+  for r in ranks:                                            # plans are mutually consistent
+    for name, (pl, n_owned) in partition.tables_of(r).items():
+      assert pl.recv_counts.sum() == len(pl.halo_global)
+      for q, other in enumerate(ranks):
+        assert len(partition.tables_of(other)[name][0].send_local[r.rank]) == pl.recv_counts[q]
+      assert pl.recv_counts[r.rank] == 0
+  if n_parts == 1:
+    assert all(len(partition.tables_of(ranks[0])[k][0].halo_global) == 0 for k in ("g2m", "mesh", "m2g"))
+
+
+@pytest.mark.parametrize("n_parts", [2, 5])
+def test_local_exchange_reproduces_global_gathers(graphs, n_parts):
+  """After an exchange, table_local[local senders] == table_global[global senders] for every
+  edge a rank owns -- the only thing the edge kernels need from other ranks."""
+  g, glon, mlon = graphs
+  ranks = partition.plan(g, glon, mlon, n_parts)
+  rng = np.random.default_rng(0)
+  for name, key, n_glob, owned_attr in (("g2m", "g2m", g["n_grid"], "grid_owned"),
+                                        ("mesh", "mesh", g["n_mesh"], "mesh_owned"),
+                                        ("m2g", "m2g", g["n_mesh"], "mesh_owned")):
+    table = rng.standard_normal((n_glob, 8)).astype(np.float32)
+    locals_ = []
+    for r in ranks:
+      pl, n_owned = partition.tables_of(r)[name]
+      t = torch.full((n_owned + len(pl.halo_global), 8), float("nan"))
+      t[:n_owned] = torch.from_numpy(table[getattr(r, owned_attr)])
+      locals_.append(t)
+    partition.LocalExchanger([partition.tables_of(r)[name][0] for r in ranks],
+                             [partition.tables_of(r)[name][1] for r in ranks]).exchange(locals_)
+    for r, t in zip(ranks, locals_):
+      e = r.graphs[key]
+      want = table[np.asarray(g[key]["senders"])[e["edge_ids"]]]
+      np.testing.assert_array_equal(t.numpy()[e["senders"]], want)
+      assert not torch.isnan(t).any()
+
+
+def test_dist_exchanger_over_gloo(tmp_path):
+  """world_size 2: the same check through DistExchanger / all_to_all_single."""
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  procs = []
+  for rank in range(2):
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_partition_worker.py")], env=env))
+  for p in procs:
+    assert p.wait(timeout=300) == 0
