@@ -255,7 +255,10 @@ __device__ __forceinline__ void split8(f4 a, f4 b, u4& hi, u4& lo) {
 // issued between the MFMAs of a round: on this chip an instruction wedged between two
 // back-to-back MFMAs costs far more than its own issue slot (measured here: weaving the
 // swish / fp16-split VALU work of the next K step into the stream made the step slower, not
-// faster), so VALU work runs in bursts at chunk boundaries instead.
+// faster), so VALU work runs in bursts at chunk boundaries instead.  (A finer weave -- the 80
+// VALU instructions cut into 40 micro-steps of <= 2, one behind each of the first 40 MFMAs,
+// which scripts/ubench/mfma_issue.hip shows to be free in isolation -- measured equal to the
+// burst in the real kernel, within noise, and was dropped for simplicity.)
 //
 // GC_PIPE == 2 (default): the workgroup barrier that publishes the NEXT chunk sits INSIDE the
 // last group, between 2 and 3, and step 3 then requests the next chunk's first fragments: the

@@ -21,6 +21,8 @@ __device__ __forceinline__ f4 mm32(float a, float b, f4 c) {
 // MODE 2: 32 accumulators, every MFMA on a different accumulator round-robin (no near dependence)
 // MODE 3: MODE 0 + 8 ds_read_b128 per group (fragments from LDS, prefetched one group ahead)
 // MODE 4: fp32 16x16x4 reference: 32 accumulators round robin
+// MODE 5/6/7: MODE 0 with 1 / 2 / 3 independent VALU ops (v_fma) wedged after EVERY MFMA
+// MODE 8: MODE 0 with one transcendental (v_exp) + one v_fma after every second MFMA
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k(const u4* __restrict__ src, f4* out, long long* cyc, int iters) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -64,6 +66,29 @@ __global__ __launch_bounds__(256, 1) void k(const u4* __restrict__ src, f4* out,
           for (int q = 0; q < 4; ++q) acc[4 * T + q] = mm(al[q], bh, acc[4 * T + q]);
         }
       }
+    } else if (MODE >= 5 && MODE <= 8) {
+      float va = __builtin_bit_cast(float, bh.x), vb = __builtin_bit_cast(float, bl.x);
+      float v0 = va, v1 = vb, v2 = va + 1.f;
+#pragma unroll
+      for (int T = 0; T < 8; ++T) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[4 * T + q] = mm(r == 2 ? al[q] : ah[q], r == 1 ? bl : bh, acc[4 * T + q]);
+            if (MODE == 8) {
+              if (q & 1) { v0 = __builtin_amdgcn_exp2f(v0); v1 = __builtin_fmaf(v1, va, vb); }
+            } else {
+              v0 = __builtin_fmaf(v0, va, vb);
+              if (MODE >= 6) v1 = __builtin_fmaf(v1, vb, va);
+              if (MODE >= 7) v2 = __builtin_fmaf(v2, va, va);
+            }
+            asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      acc[0].x += v0 + v1 + v2;
     } else if (MODE == 1) {
 #pragma unroll
       for (int T = 0; T < 4; ++T) {
@@ -131,6 +156,10 @@ int main() {
     run<2>("f16 round-robin 32 accumulators", blocks, src, out, cyc);
     run<3>("f16 groups of 4 + LDS fragments", blocks, src, out, cyc);
     run<4>("f32 16x16x4 round-robin", blocks, src, out, cyc);
+    run<5>("f16 g4 + 1 VALU after each MFMA", blocks, src, out, cyc);
+    run<6>("f16 g4 + 2 VALU after each MFMA", blocks, src, out, cyc);
+    run<7>("f16 g4 + 3 VALU after each MFMA", blocks, src, out, cyc);
+    run<8>("f16 g4 + exp,fma per 2 MFMA", blocks, src, out, cyc);
   }
   return 0;
 }
