@@ -32,6 +32,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #ifndef GC_SCHED_PIN
 #define GC_SCHED_PIN 1
 #endif
+#ifndef GC_DMA_LEAD
+#define GC_DMA_LEAD 2    // trailing MFMA groups of a chunk that issue no weight DMA (it must have landed
+#endif                   // by the in-group barrier of the last one)
 #ifndef GC_DMA_ASM
 #define GC_DMA_ASM 1     // LDS-DMA as inline asm (see stage_piece)
 #endif
@@ -277,7 +280,7 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
   constexpr int kGroups = (NBLK + 3) / 4;
   constexpr int n0 = 4 * T;
   constexpr int cnt = NBLK - n0 < 4 ? NBLK - n0 : 4;
-  constexpr int kDmaGroups = (GC_PIPE == 2 && kGroups > 2) ? kGroups - 2 : kGroups;
+  constexpr int kDmaGroups = (GC_PIPE == 2 && kGroups > GC_DMA_LEAD) ? kGroups - GC_DMA_LEAD : kGroups;
   constexpr int kPpg = (PIECES + kDmaGroups - 1) / kDmaGroups;
   constexpr bool more = T + 1 < kGroups;
   constexpr bool cross = !more && NEXT && GC_PIPE == 2;

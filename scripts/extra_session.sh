@@ -10,3 +10,6 @@ echo "pytest rc=$?"; grep -E "parts:|rollout|passed|failed|Error" "$OUT/pytest.l
 echo "== rollout bench (config 3)"
 timeout 900 python scripts/rollout_bench.py --steps ${ROLLOUT_STEPS:-40} --out "$OUT/rollout.json" > "$OUT/rollout.log" 2>&1
 echo "rollout rc=$?"; tail -3 "$OUT/rollout.log" | cut -c1-800
+echo "== partition emulated bench (config 5)"
+timeout 900 python scripts/partition_emulated_bench.py --parts ${PARTS:-8} --out "$OUT/partition.json" > "$OUT/partition.log" 2>&1
+echo "partition rc=$?"; tail -2 "$OUT/partition.log" | cut -c1-1500
