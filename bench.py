@@ -140,7 +140,7 @@ def main():
   ap.add_argument("--config", default="0.25deg_37L_M6", choices=sorted(CONFIGS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--op-timing-iters", type=int, default=2)
-  ap.add_argument("--precision", default=None, choices=["f16x3", "f32"],
+  ap.add_argument("--precision", default=None, choices=["f16x3", "f32", "bf16"],
                   help="GEMM arithmetic (include/gcast.h gc_precision); default: engine default")
   ap.add_argument("--no-cross-check", action="store_true",
                   help="skip the full-size f16x3-vs-f32-MFMA agreement check (N = 1 only)")
@@ -246,7 +246,7 @@ def main():
     achieved = dom["tflop"] / (dom["ms"] / 1e3) if dom["ms"] > 0 else 0.0
     executed_tflop = sum(s["tflop"] for s in per_stage.values())
     split = precision == "f16x3"
-    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
     issue = 3.0 if split else 1.0            # MFMA FLOPs issued per algorithmic FLOP
     line = {
         "metric": "6-h rollout steps/sec at 0.25deg/37-level",
@@ -257,7 +257,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 (3 x f16-split MFMA products, f32 accumulate)" if split else "f32",
+        "dtype": {"f16x3": "f32 (3 x f16-split MFMA products, f32 accumulate)", "f32": "f32",
+                  "bf16": "bf16 GEMM operands, f32 accumulate (reduced-precision TIER: not the headline)"}[precision],
         "data": "synthetic",
         "config": {
             "workload": f"GraphCast {args.config}: one encode-process-decode 6-h step per GPU "
@@ -268,7 +269,8 @@ def main():
             "batch_per_gpu": 1},
         "roofline": {
             "bound": "mfma",
-            "kernel": f"{'rowmlp16_kernel' if split else 'rowmlp_kernel'}<MLP_LN> stage {dominant}",
+            "kernel": f"{ {'f16x3': 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16': 'rowmlpb_kernel'}[precision] }"
+                      f"<MLP_LN> stage {dominant}",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,
             "mfma_flops_per_algorithmic_flop": issue,

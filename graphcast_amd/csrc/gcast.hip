@@ -896,6 +896,288 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
 #endif
 }
 
+// ---- GC_PREC_BF16 -----------------------------------------------------------------------
+// The tier the published GraphCast demo runs (casting.Bfloat16Cast, utils/casting.py:31-65): GEMM
+// operands rounded to bfloat16 (round to nearest even), ONE v_mfma_f32_16x16x32_bf16 per product,
+// fp32 accumulation.  Everything between the GEMMs (bias, addends, swish, LayerNorm, residual,
+// segment-sum) stays fp32 here -- more precise than the reference's all-bf16 activations, so this
+// is NOT the fp32-tolerance path; it is checked against an oracle that rounds the same operands.
+// Same register-chained structure as the split-f16 kernel, half the LDS image (no lo halves),
+// groups of eight n-blocks so that eight MFMAs still cover the next group's fragment reads.
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f4 mfma32b(u4 a, u4 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b),
+                                                 c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {     // v_cvt_pk_bf16_f32 (RNE)
+  const f2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+
+__device__ __forceinline__ u4 pack8bf(f4 a, f4 b) {
+  return u4{pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w)};
+}
+
+__device__ __forceinline__ float swish1(float x);
+
+__device__ __forceinline__ u4 swish_pack8bf(f4 a, f4 b) {
+  return u4{pack2bf(swish1(a.x), swish1(a.y)), pack2bf(swish1(a.z), swish1(a.w)),
+            pack2bf(swish1(b.x), swish1(b.y)), pack2bf(swish1(b.z), swish1(b.w))};
+}
+
+__device__ __forceinline__ void loadb_first_frags(const float* wbuf, int lane, u4 (&fa)[8]) {
+  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) fa[q] = wb[q * 64];
+}
+
+// Group T = eight n-blocks = eight MFMAs; the next group's eight fragment reads are requested
+// first and stay in flight behind them; the last group of a chunk carries the publishing
+// barrier and the next chunk's first fragment reads between its two halves.
+template <int NBLK, int PIECES, int T, bool NEXT>
+__device__ __forceinline__ void mmab_group(f4 (&acc)[kNB], const u4* wb, const u4* wb_next,
+                                           const u4 (&a)[8], u4 (&o)[8], u4 b,
+                                           const float* __restrict__ next_src, float* next_dst,
+                                           int wave, int lane) {
+  constexpr int kGroups = (NBLK + 7) / 8;
+  constexpr int n0 = 8 * T;
+  constexpr int cnt = NBLK - n0 < 8 ? NBLK - n0 : 8;
+  constexpr int kDmaGroups = kGroups > 2 ? kGroups - 2 : 1;
+  constexpr int kPpg = (PIECES + kDmaGroups - 1) / kDmaGroups;
+  constexpr bool more = T + 1 < kGroups;
+  constexpr bool cross = !more && NEXT;
+  constexpr int cnt2 = more ? (NBLK - n0 - 8 < 8 ? NBLK - n0 - 8 : 8) : 0;
+  if constexpr (T < kDmaGroups) {
+#pragma unroll
+    for (int p = 0; p < kPpg; ++p) {
+      if (T * kPpg + p < PIECES) stage_piece(next_src, next_dst, T * kPpg + p, wave, lane);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  u4 n[8];
+  if constexpr (!cross) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) n[q] = q < cnt2 ? wb[(n0 + 8 + q) * 64] : a[q];
+    __builtin_amdgcn_s_waitcnt(0xC07F | (cnt2 << 8));      // this group's fragments have landed
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32b(a[q], b, acc[n0 + q]);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    constexpr int half = (cnt + 1) / 2;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < half; ++q) acc[n0 + q] = mfma32b(a[q], b, acc[n0 + q]);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_wait();
+    __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
+#pragma unroll
+    for (int q = 0; q < 8; ++q) n[q] = wb_next[q * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = half; q < cnt; ++q) acc[n0 + q] = mfma32b(a[q], b, acc[n0 + q]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (more) {
+    mmab_group<NBLK, PIECES, T + 1, NEXT>(acc, wb, wb_next, n, o, b, next_src, next_dst, wave, lane);
+  } else if constexpr (cross) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = n[q];
+  }
+}
+
+template <int NBLK, int PIECES, bool NEXT>
+__device__ __forceinline__ void mmab_chunk(f4 (&acc)[kNB], const float* wbuf, float* wnext, u4 (&fa)[8],
+                                           u4 b, const float* __restrict__ next_src, int wave, int lane) {
+  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
+  const u4* wbn = reinterpret_cast<const u4*>(wnext) + lane;
+  mmab_group<NBLK, PIECES, 0, NEXT>(acc, wb, wbn, fa, fa, b, next_src, wnext, wave, lane);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void rowmlpb_kernel(const gc_rowmlp_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool kLinear = MODE == GC_MODE_LINEAR;
+  constexpr int NP2 = MODE == GC_MODE_MLP_OUT ? 256 : 512;
+  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
+  constexpr int kPieces1 = 512 / 64;       // 1 KiB-per-wave DMA pieces of a 32 KiB layer-1 chunk
+  constexpr int kPieces2 = NP2 / 64;
+  constexpr int kChunk1 = 512 * 16;        // floats per packed K chunk (bf16: NP * 64 bytes)
+  constexpr int kChunk2 = NP2 * 16;
+  constexpr int kPairs = kNB / 2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i = lane & 15;
+  const int g = lane >> 4;
+  const int tile = blockIdx.x;
+  const int row = tile * GC_TILE_ROWS + wave * 16 + i;
+  const int rowc = row < d.n_rows ? row : d.n_rows - 1;
+  const int col0 = 4 * g;
+  const float* w1p = static_cast<const float*>(d.w1p);   // opaque 64 KiB chunks
+  const float* w2p = static_cast<const float*>(d.w2p);
+
+  const int n1 = (d.k0 + d.k1) >> 5;
+  const int n1a = d.k0 >> 5;
+  int q = 0;
+  GC_MARK(0);
+#if GC_TRACE
+  if (!d.seg && d.partial && threadIdx.x == 0) {
+    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 9] = __smid();
+  }
+#endif
+
+  if (n1 > 0) {
+    stage_chunk<256>(w1p, smem, tid);
+  } else if (!kLinear) {
+    stage_chunk<NP2 / 2>(w2p, smem, tid);
+  }
+
+  // The addends b1 + d[row] + g0[idx0[row]] + g1[idx1[row]] are NOT loaded up front: a 64-row
+  // tile of them is up to 384 KiB, a phase of its own at the f16 rate.  They are streamed one
+  // n-block pair per chunk behind the MFMAs (staged in `t` one chunk, summed into `add` the next).
+  const float* b1row = (d.b1 ? d.b1 : g_zero_row) + col0;
+  AddendRows ar;
+  ar.dd = (d.d ? d.d + (size_t)rowc * d.ldd : g_zero_row) + col0;
+  ar.g0 = g_zero_row + col0;
+  ar.g1 = g_zero_row + col0;
+  if (d.g0) {
+    int ix = d.idx0[rowc];
+    ix = ix < 0 ? 0 : ix;
+    ar.g0 = d.g0 + (size_t)ix * kD + col0;
+  }
+  if (d.g1) {
+    int ix = d.idx1[rowc];
+    ix = ix < 0 ? 0 : ix;
+    ar.g1 = d.g1 + (size_t)ix * kD + col0;
+  }
+
+  // The accumulators start from the bias (in the weights' scaled space); the per-row addends are
+  // streamed behind layer 2 (below).
+  f4 acc[kNB];
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) acc[nb] = d.w1_scale * *reinterpret_cast<const f4*>(b1row + nb * 16);
+  f4 t0[6];               // addend staging: loads of one n-block pair in flight behind the MFMAs
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  u4 fa[8];               // fragments of the next eight n-blocks, carried across chunks
+  {
+    dma_wait();
+    __syncthreads();      // the chunk staged in the prologue
+    loadb_first_frags(smem, lane, fa);
+  }
+  GC_MARK(1);
+  float* const buf0 = smem;
+  float* const buf1 = smem + kBufFloats;
+  const float inv1 = 1.0f / d.w1_scale;         // exact: powers of two
+  const float inv2 = 1.0f / d.w2_scale;
+
+  // ---- layer 1: the lane's 8 consecutive k of its row per chunk, split in registers ----
+  if (n1 > 0) {
+    const float* arow0 = d.a0 + (size_t)rowc * d.lda0 + 8 * g;
+    const float* arow1 = d.k1 ? d.a1 + (size_t)rowc * d.lda1 + 8 * g : arow0;
+    f4 xc0, xc1, xn0, xn1;
+    {
+      const float* p = n1a > 0 ? arow0 : arow1;
+      xc0 = *reinterpret_cast<const f4*>(p);
+      xc1 = *reinterpret_cast<const f4*>(p + 4);
+    }
+    xn0 = xc0;
+    xn1 = xc1;
+    u4 bb;
+    for (int c = 0; c + 1 < n1; ++c) {
+      {
+        const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
+        xn0 = *reinterpret_cast<const f4*>(p);
+        xn1 = *reinterpret_cast<const f4*>(p + 4);
+      }
+      bb = pack8bf(xc0, xc1);
+      mmab_chunk<kNB, kPieces1, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb, w1p + (size_t)(c + 1) * kChunk1, wave_u, lane);
+      xc0 = xn0;
+      xc1 = xn1;
+      ++q;
+    }
+    bb = pack8bf(xc0, xc1);
+    if (kLinear) {
+      mmab_chunk<kNB, 0, false>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb,
+                                 nullptr, wave_u, lane);
+    } else {
+      mmab_chunk<kNB, kPieces2, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb, w2p, wave_u, lane);
+    }
+    ++q;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) acc[nb] *= inv1;
+  }
+  GC_MARK(2);
+
+  if (kLinear) {
+    if (d.d || d.g0 || d.g1) {   // per-row addends of a LINEAR launch (load-time folding only): eager
+#pragma unroll
+      for (int p = 0; p < kPairs; ++p) {
+        f4 a, b;
+        ar.issue(p, t0);
+        sum_pair(t0, a, b);
+        acc[2 * p] += a;
+        acc[2 * p + 1] += b;
+        __builtin_amdgcn_sched_barrier(0);     // (keeps the 128 loads from being hoisted together)
+      }
+    }
+    store_linear(acc, d, row, col0);
+    return;
+  }
+
+  // ---- layer 2.  K step cc consumes hidden blocks (2cc, 2cc+1) = swish(acc + addends).  The
+  // addends of pair cc+2 are requested at the top of step cc and summed at the top of step cc+1,
+  // so their latency hides behind a whole K step of MFMAs; the swish + fp16 split of pair cc+1
+  // runs as ONE VALU burst at the top of step cc (instructions wedged between back-to-back
+  // MFMAs cost far more than they hide: MI355X_MICROARCH.md, "one extra issue slot").
+  u4 sw;
+  ar.issue(0, t0);
+  {
+    f4 za, zb;
+    sum_pair(t0, za, zb);
+    ar.issue(1, t0);
+    sw = swish_pack8bf(za + acc[0], zb + acc[1]);
+  }
+  GC_MARK(3);
+  f4 o2[kNB];
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb) o2[nb] = d.w2_scale * *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
+#pragma unroll
+  for (int cc = 0; cc < kPairs; ++cc) {
+    const u4 bb2 = sw;
+    if (cc + 1 < kPairs) {
+      f4 za, zb;
+      sum_pair(t0, za, zb);
+      za += acc[2 * cc + 2];
+      zb += acc[2 * cc + 3];
+      if (cc + 2 < kPairs) ar.issue(cc + 2, t0);
+      sw = swish_pack8bf(za, zb);
+      mmab_chunk<NB2, kPieces2, true>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb2, w2p + (size_t)(cc + 1) * kChunk2, wave_u, lane);
+    } else {
+      mmab_chunk<NB2, 0, false>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb2,
+                                 nullptr, wave_u, lane);
+    }
+    ++q;
+  }
+  GC_MARK(4);
+#pragma unroll
+  for (int nb = 0; nb < NB2; ++nb) o2[nb] *= inv2;
+  finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
+  GC_MARK(5);
+#if GC_TRACE
+  if (!d.seg && d.partial && threadIdx.x == 0)
+    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
+#endif
+}
+
 __global__ void seg_fixup_kernel(int n, const int* __restrict__ recv, const int* __restrict__ t0,
                                  const int* __restrict__ t1, const float* __restrict__ partial,
                                  float* __restrict__ agg) {
@@ -976,15 +1258,16 @@ int check_launch(const char* what) {
   return 0;
 }
 
-bool g_attr_set[2][3] = {{false, false, false}, {false, false, false}};
+bool g_attr_set[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
 
 template <int MODE>
 int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = kLdsFloats * sizeof(float);
-  const bool split = d.prec == GC_PREC_F16X3;
+  const int split = d.prec;      // 0 f32, 1 f16x3, 2 bf16
   if (!g_attr_set[split][MODE]) {
-    const void* fn = split ? reinterpret_cast<const void*>(&rowmlp16_kernel<MODE>)
-                           : reinterpret_cast<const void*>(&rowmlp_kernel<MODE>);
+    const void* fn = split == GC_PREC_F16X3 ? reinterpret_cast<const void*>(&rowmlp16_kernel<MODE>)
+                     : split == GC_PREC_BF16 ? reinterpret_cast<const void*>(&rowmlpb_kernel<MODE>)
+                                             : reinterpret_cast<const void*>(&rowmlp_kernel<MODE>);
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
@@ -993,8 +1276,10 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
     g_attr_set[split][MODE] = true;
   }
   const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
-  if (split) {
+  if (split == GC_PREC_F16X3) {
     hipLaunchKernelGGL(rowmlp16_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
+  } else if (split == GC_PREC_BF16) {
+    hipLaunchKernelGGL(rowmlpb_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
   } else {
     hipLaunchKernelGGL(rowmlp_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
   }
@@ -1021,10 +1306,11 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (d.w1_scale == 0.f || d.k0 + d.k1 == 0) d.w1_scale = 1.f;   // (no layer-1 weights: nothing is scaled)
   if (d.w2_scale == 0.f) d.w2_scale = 1.f;
   if (d.prec == GC_PREC_F32 && (d.w1_scale != 1.f || d.w2_scale != 1.f))
-    return fail(GC_EINVAL, "gc_rowmlp: weight scales are a GC_PREC_F16X3 feature");
+    return fail(GC_EINVAL, "gc_rowmlp: weight scales are not a GC_PREC_F32 feature");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
-  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3) return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
+  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16)
+    return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
   if (d.reserved0 != 0) return fail(GC_EINVAL, "gc_rowmlp: reserved0 must be 0");
   if ((d.k0 | d.k1) & 31 || d.k0 < 0 || d.k1 < 0) return fail(GC_EINVAL, "gc_rowmlp: k0/k1 must be multiples of 32");
   if (d.k0 == 0 && d.k1 != 0) return fail(GC_EINVAL, "gc_rowmlp: k1 without k0");
@@ -1170,7 +1456,7 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR2(x) #x
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
-  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32;pipe=" GC_STR(GC_PIPE);
+  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;pipe=" GC_STR(GC_PIPE);
 }
 
 }  // extern "C"

@@ -30,8 +30,10 @@ from graphcast_amd import packing
 D = packing.LATENT
 
 # Arithmetic of the GEMMs (include/gcast.h `gc_precision`): "f16x3" = fp32 operands split into
-# two halves in registers, three f16 MFMAs per product, fp32 accumulation (fp32-grade results,
-# ~5x the fp32-MFMA rate); "f32" = exact fp32 MFMA.  Overridable with GCAST_PRECISION.
+# two halves in registers, three f16 MFMAs per product, fp32 accumulation (fp32-grade results);
+# "f32" = exact fp32 MFMA; "bf16" = the reduced-precision tier of the reference's Bfloat16Cast
+# (GEMM operands rounded to bfloat16; NOT within the fp32 tolerance).  Overridable with
+# GCAST_PRECISION.
 DEFAULT_PRECISION = "f16x3"
 
 # stage tags reported by gc_time_program / used by bench.py
@@ -76,6 +78,10 @@ class _Mlp:
         sc = packing.choose_weight_scale(w)
         return _PW(up(packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc)
                       .view(np.int16)), sc)
+    elif prec == nat.PREC_BF16:
+      pack1 = lambda w: _PW(up(packing.pack_weight_bf16(w).view(np.int16)))
+      pack2 = lambda w, np_cols: _PW(up(packing.pack_weight_bf16(w, np_cols=np_cols, chained=True)
+                                       .view(np.int16)))
     else:
       pack1 = lambda w: _PW(up(packing.pack_weight(w)))
       pack2 = lambda w, np_cols: _PW(up(packing.pack_weight(w, np_cols=np_cols)))

@@ -121,6 +121,7 @@ class GraphCast(predictor_base.Predictor):
     self._params = params
     self._initialized = False
     self._engine = None
+    self._engines = {}
     self._grid2mesh_graph_structure = None
     self._mesh_graph_structure = None
     self._mesh2grid_graph_structure = None
@@ -129,6 +130,18 @@ class GraphCast(predictor_base.Predictor):
   def load_params(self, params: Mapping[str, Mapping[str, Any]]) -> None:
     self._params = params
     self._engine = None
+    self._engines = {}
+
+  def set_precision(self, precision: Optional[str]) -> Optional[str]:
+    """Selects the GEMM arithmetic ("f16x3" | "f32" | "bf16", None = default); returns the
+    previous setting.  Engines are cached per precision (each holds its own packed weights)."""
+    prev = self._precision
+    if precision != prev:
+      if self._engine is not None:
+        self._engines[prev] = self._engine
+      self._engine = self._engines.get(precision)
+      self._precision = precision
+    return prev
 
   @property
   def _finest_mesh(self):

@@ -99,6 +99,34 @@ def pack_weight_split(w, np_cols=LATENT, chained=False, scale=1.0):
   return np.ascontiguousarray(out.reshape(kp // K_CHUNK, np_cols // 16, 2, 64, 8)).view(np.uint16)
 
 
+def bf16_bits(x):
+  """float32 -> bfloat16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does)."""
+  u = np.ascontiguousarray(np.asarray(x, dtype=np.float32)).view(np.uint32)
+  return ((u + (((u >> 16) & 1) + np.uint32(0x7FFF))) >> 16).astype(np.uint16)
+
+
+def bf16_round(x):
+  """float32 -> the nearest bfloat16, returned as float32."""
+  return (bf16_bits(x).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(x))
+
+
+def pack_weight_bf16(w, np_cols=LATENT, chained=False):
+  """[K, N] float32 -> uint16 [ceil32(K)/32, np_cols/16, 64, 8]: the GC_PREC_BF16 layout of
+  include/gcast.h (the hi-only analogue of ``pack_weight_split``, same K maps)."""
+  w = np.asarray(w, dtype=np.float32)
+  k, n = w.shape
+  if n > np_cols:
+    raise ValueError(f"weight has {n} columns, packed layout holds {np_cols}")
+  kp = round_up(k, K_CHUNK)
+  padded = np.zeros((kp, np_cols), dtype=np.float32)
+  padded[:k, :n] = w
+  bits = bf16_bits(padded)
+  km = _kmap(chained)
+  blk = bits.reshape(kp // K_CHUNK, K_CHUNK, np_cols // 16, 16)              # [c, k, nb, n]
+  out = blk[:, km, :, :].transpose(0, 3, 1, 4, 2)                            # [c, nb, g, n, j]
+  return np.ascontiguousarray(out.reshape(kp // K_CHUNK, np_cols // 16, 64, 8))
+
+
 def unpack_weight_split(wp, k, n, chained=False):
   """Inverse of pack_weight_split -> (hi, lo) float32 [k, n] (tests)."""
   wp = np.asarray(wp).view(np.float16)

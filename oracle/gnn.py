@@ -36,7 +36,36 @@ def swish(x):
     return x / (1.0 + np.exp(-x))
 
 
+# None, or "bf16": round BOTH operands of every Linear product to bfloat16 (nearest even) before
+# multiplying, accumulate in the working dtype -- the arithmetic of the GC_PREC_BF16 tier (the
+# GEMM-operand part of the reference's casting.Bfloat16Cast, utils/casting.py:31-65,155-205).
+GEMM_OPERANDS = None
+
+
+class gemm_operands:
+  """Context manager: ``with gnn.gemm_operands("bf16"): ...``"""
+
+  def __init__(self, mode):
+    self.mode = mode
+
+  def __enter__(self):
+    global GEMM_OPERANDS
+    self.prev, GEMM_OPERANDS = GEMM_OPERANDS, self.mode
+
+  def __exit__(self, *exc):
+    global GEMM_OPERANDS
+    GEMM_OPERANDS = self.prev
+
+
+def _bf16(a):
+  u = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.uint32)
+  r = ((u + (((u >> 16) & 1) + np.uint32(0x7FFF))) >> 16) << 16
+  return r.view(np.float32).astype(np.asarray(a).dtype)
+
+
 def linear(x, w, b):
+  if GEMM_OPERANDS == "bf16":
+    x, w = _bf16(x), _bf16(w)
   # 2-D GEMM: numpy would treat [rows, batch, k] @ [k, n] as `rows` tiny [batch, k] products
   return (x.reshape(-1, x.shape[-1]) @ w).reshape(x.shape[:-1] + (w.shape[1],)) + b
 

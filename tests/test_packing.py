@@ -156,3 +156,21 @@ def test_split_product_error_is_fp32_class():
   got = xh @ wh + xl @ wh + xh @ wl
   want = x.astype(np.float64) @ w
   assert np.linalg.norm(got - want) / np.linalg.norm(want) < 6e-7   # fp32 sgemm: 3e-7
+
+
+def test_bf16_rounding_and_layout():
+  torch = pytest.importorskip("torch")
+  rng = np.random.default_rng(3)
+  x = (rng.standard_normal(50000) * np.exp(rng.uniform(-20, 20, 50000))).astype(np.float32)
+  want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+  np.testing.assert_array_equal(packing.bf16_round(x), want)            # round to nearest even
+  w = (rng.standard_normal((474, 227)) / 20).astype(np.float32)
+  for chained in (False, True):
+    wp = packing.pack_weight_bf16(w, np_cols=256, chained=chained)
+    assert wp.shape == (15, 16, 64, 8) and wp.dtype == np.uint16
+    v = (wp.astype(np.uint32) << 16).view(np.float32)
+    for (c, nb, g, n, j) in [(0, 0, 0, 0, 0), (14, 14, 3, 2, 7), (3, 7, 2, 5, 3), (3, 7, 2, 5, 4)]:
+      kk = 32 * c + ((4 * g + j if j < 4 else 16 + 4 * g + j - 4) if chained else 8 * g + j)
+      col = 16 * nb + n
+      expect = packing.bf16_round(w)[kk, col] if (kk < 474 and col < 227) else 0.0
+      assert v[c, nb, 16 * g + n, j] == expect

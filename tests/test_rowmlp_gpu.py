@@ -18,12 +18,12 @@ from graphcast_amd import packing                 # noqa: E402
 from oracle import gnn as ognn                    # noqa: E402
 
 D = 512
-REL_RMSE_TOL = {"f32": 2e-6, "f16x3": 3e-6}
+REL_RMSE_TOL = {"f32": 2e-6, "f16x3": 3e-6, "bf16": 3e-6}    # bf16: vs the oracle that rounds the same operands
 MAX_ABS_TOL = 2e-4
 _PREC = "f32"          # set per test by the autouse fixture below
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "bf16"])
 def prec(request):
   global _PREC
   _PREC = request.param
@@ -45,7 +45,15 @@ def pw1(w):
     img = packing.pack_weight_split(w, scale=sc).view(np.int16).view(Image)
     img.scale = sc
     return img
+  if _PREC == "bf16":
+    return packing.pack_weight_bf16(w).view(np.int16)
   return packing.pack_weight(w)
+
+
+def r16(a):
+  """What the current arithmetic mode does to a GEMM operand before multiplying (float64 out)."""
+  a = np.asarray(a)
+  return packing.bf16_round(a.astype(np.float32)).astype(np.float64) if _PREC == "bf16" else a.astype(np.float64)
 
 
 def pw2(w, np_cols=D):
@@ -55,6 +63,8 @@ def pw2(w, np_cols=D):
     img = packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc).view(np.int16).view(Image)
     img.scale = sc
     return img
+  if _PREC == "bf16":
+    return packing.pack_weight_bf16(w, np_cols=np_cols, chained=True).view(np.int16)
   return packing.pack_weight(w, np_cols=np_cols)
 
 
@@ -121,7 +131,7 @@ def test_linear_mode(dev, n_rows, k):
   d.a0, d.lda0, d.k0, d.w1p, d.b1 = ta.data_ptr(), k, k, tw.data_ptr(), tb.data_ptr()
   d.out, d.ldo = out.data_ptr(), D
   run(d)
-  assert_close(out.cpu().numpy(), a.astype(np.float64) @ w + b1, f"linear k={k}")
+  assert_close(out.cpu().numpy(), r16(a) @ r16(w) + b1, f"linear k={k}")
 
 
 def test_linear_identity_weight_detects_transposes(dev):
@@ -135,6 +145,8 @@ def test_linear_identity_weight_detects_transposes(dev):
   run(d)
   if _PREC == "f32":
     np.testing.assert_array_equal(out.cpu().numpy(), a)   # exact: one product per output
+  elif _PREC == "bf16":
+    np.testing.assert_array_equal(out.cpu().numpy(), packing.bf16_round(a))
   else:                                                    # x_hi + x_lo: 22 of x's 24 bits
     np.testing.assert_allclose(out.cpu().numpy(), a, rtol=2.0 ** -21, atol=2.0 ** -24)
 
@@ -158,7 +170,7 @@ def test_linear_with_gathers_and_direct_addend(dev):
   d.g0, d.idx0, d.g1, d.idx1 = t[3].data_ptr(), ti0.data_ptr(), t[4].data_ptr(), ti1.data_ptr()
   d.out, d.ldo = out.data_ptr(), D
   run(d)
-  want = a.astype(np.float64) @ w + dd + g0[i0] + g1[i1]
+  want = r16(a) @ r16(w) + dd + g0[i0] + g1[i1]
   assert_close(out.cpu().numpy(), want, "linear+gathers")
 
 
@@ -179,8 +191,8 @@ def _mlp_ln_want(p, extra=0.0):
   z = extra + p["b1"].astype(np.float64)
   if p["a0"] is not None:
     a = p["a0"] if p["a1"] is None else np.concatenate([p["a0"], p["a1"]], axis=1)
-    z = z + a.astype(np.float64) @ p["w1"]
-  y = ognn.swish(z) @ p["w2"].astype(np.float64) + p["b2"]
+    z = z + r16(a) @ r16(p["w1"])
+  y = r16(ognn.swish(z)) @ r16(p["w2"]) + p["b2"]
   return ognn.layer_norm(y, p["scale"].astype(np.float64), p["offset"].astype(np.float64))
 
 
@@ -296,7 +308,7 @@ def test_mlp_out_mode(dev, n_rows, n2, batch):
   b = batch - 1
   d.out, d.ldo = out.data_ptr() + 4 * b * n2, batch * n2
   run(d)
-  want = ognn.swish(a.astype(np.float64) @ w1 + b1) @ w2.astype(np.float64) + b2
+  want = r16(ognn.swish(r16(a) @ r16(w1) + b1)) @ r16(w2) + b2
   got = out.cpu().numpy()
   assert_close(got[:, b, :], want, f"mlp_out n2={n2}")
   if batch > 1:

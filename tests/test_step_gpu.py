@@ -20,7 +20,7 @@ def rel_rmse(got, want):
   return float(np.linalg.norm(np.asarray(got, np.float64) - want) / np.linalg.norm(want))
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f32", "bf16"])
 def small(request):
   if not torch.cuda.is_available():
     pytest.fail("GPU test selected but no GPU is visible")
@@ -49,7 +49,9 @@ def test_product_graphs_equal_oracle_graphs(small):
 def test_step_matches_oracle(small, batch):
   rng = np.random.default_rng(batch)
   x = rng.standard_normal((small["graphs"]["n_grid"], batch, small["c_in"])).astype(np.float32)
-  want = ogc.forward(small["params"], small["graphs"], x, steps=small["steps"], dtype=np.float64)
+  from oracle import gnn as ognn
+  with ognn.gemm_operands("bf16" if small["precision"] == "bf16" else None):   # same operand rounding
+    want = ogc.forward(small["params"], small["graphs"], x, steps=small["steps"], dtype=np.float64)
   y = small["model"].forward_grid_node_features(torch.from_numpy(x).to("cuda:0"))
   torch.cuda.synchronize()
   got = y.cpu().numpy()
@@ -60,6 +62,9 @@ def test_step_matches_oracle(small, batch):
   assert err <= REL_RMSE_TOL
   for b in range(batch):                        # per batch element too
     assert rel_rmse(got[:, b], want[:, b]) <= REL_RMSE_TOL
+  if small["precision"] == "bf16":              # the tier is NOT fp32-grade: report how far it is
+    truth = ogc.forward(small["params"], small["graphs"], x, steps=small["steps"], dtype=np.float64)
+    print(f"bf16 tier vs float64 truth: rel-RMSE {rel_rmse(got, truth):.2e} (outside the 1e-4 fp32 budget by design)")
 
 
 def test_step_is_deterministic_and_batch_independent(small):
