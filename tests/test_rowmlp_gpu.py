@@ -18,7 +18,11 @@ from graphcast_amd import packing                 # noqa: E402
 from oracle import gnn as ognn                    # noqa: E402
 
 D = 512
-REL_RMSE_TOL = {"f32": 2e-6, "f16x3": 3e-6, "bf16": 3e-6}    # bf16: vs the oracle that rounds the same operands
+# bf16: against the oracle that rounds the same GEMM operands.  A single fused MLP already
+# differs from it by ~2e-5: the hidden activations are re-rounded to bf16, and an fp32-level
+# difference d in a pre-rounding value becomes an rms difference sqrt(d * ulp_bf16) after it.
+REL_RMSE_TOL = {"f32": 2e-6, "f16x3": 3e-6, "bf16": 5e-5}
+MAX_ABS_TOLS = {"f32": 2e-4, "f16x3": 2e-4, "bf16": 2e-2}
 MAX_ABS_TOL = 2e-4
 _PREC = "f32"          # set per test by the autouse fixture below
 
@@ -109,7 +113,7 @@ def assert_close(got, want, what):
   err = np.linalg.norm(got - want) / np.linalg.norm(want)
   assert np.isfinite(got).all(), what
   assert err <= REL_RMSE_TOL[_PREC], f"{what} [{_PREC}]: rel-RMSE {err:.3e}"
-  assert np.abs(got - want).max() <= MAX_ABS_TOL * max(1.0, np.abs(want).max()), what
+  assert np.abs(got - want).max() <= MAX_ABS_TOLS[_PREC] * max(1.0, np.abs(want).max()), what
 
 
 def asymmetric_weight(rng, k, n):
@@ -284,7 +288,7 @@ def test_edge_block_with_segment_sum(dev, case):
   got = agg.cpu().numpy()
   assert np.isfinite(got).all(), "segment-sum left poisoned rows"
   scale = max(1.0, np.abs(want).max())
-  assert np.abs(got - want).max() <= MAX_ABS_TOL * scale
+  assert np.abs(got - want).max() <= MAX_ABS_TOLS[_PREC] * scale
   assert np.linalg.norm(got - want) <= 2 * REL_RMSE_TOL[_PREC] * np.linalg.norm(want)
   # deterministic: a second run gives identical bits (no float atomics anywhere)
   first = agg.clone()

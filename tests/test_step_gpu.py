@@ -59,9 +59,13 @@ def test_step_matches_oracle(small, batch):
   err = rel_rmse(got, want)
   print(f"step rel-RMSE vs float64 oracle (batch={batch}, {small['precision']}): {err:.3e}")
   assert np.isfinite(got).all()
-  assert err <= REL_RMSE_TOL
+  # bf16 tier: two bf16 pipelines that differ only in fp32 summation order decorrelate to bf16
+  # resolution within a few layers (every re-rounding turns a difference d into sqrt(d * ulp)),
+  # so the whole step can only be pinned at that resolution
+  tol = 1.5e-2 if small["precision"] == "bf16" else REL_RMSE_TOL
+  assert err <= tol
   for b in range(batch):                        # per batch element too
-    assert rel_rmse(got[:, b], want[:, b]) <= REL_RMSE_TOL
+    assert rel_rmse(got[:, b], want[:, b]) <= tol
   if small["precision"] == "bf16":              # the tier is NOT fp32-grade: report how far it is
     truth = ogc.forward(small["params"], small["graphs"], x, steps=small["steps"], dtype=np.float64)
     print(f"bf16 tier vs float64 truth: rel-RMSE {rel_rmse(got, truth):.2e} (outside the 1e-4 fp32 budget by design)")
