@@ -32,6 +32,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #ifndef GC_SCHED_PIN
 #define GC_SCHED_PIN 1
 #endif
+#ifndef GC_RIDE
+#define GC_RIDE 1        // split-f16 path: memory instructions ride one-per-MFMA (see mma16_group)
+#endif
 #ifndef GC_DMA_LEAD
 #define GC_DMA_LEAD 2    // trailing MFMA groups of a chunk that issue no weight DMA (it must have landed
 #endif                   // by the in-group barrier of the last one)
@@ -285,13 +288,71 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
   constexpr bool more = T + 1 < kGroups;
   constexpr bool cross = !more && NEXT && GC_PIPE == 2;
   constexpr int cnt2 = more ? (NBLK - n0 - 4 < 4 ? NBLK - n0 - 4 : 4) : 0;
+  static_assert(kPpg <= 4, "at most one DMA piece behind each MFMA of the last round");
+#define GC_FENCE() __builtin_amdgcn_sched_barrier(0)
+#if GC_RIDE
+  // GC_RIDE: every memory instruction of the group rides behind ONE MFMA, fenced there
+  // (scripts/ubench/mfma_issue.hip: eight ds_read_b128 in a burst in front of twelve MFMAs cost
+  // 21.5 cycles per MFMA, one behind each of eight MFMAs 17.3 -- the bare MFMA stream is 17.1):
+  //   round 1  hi.hi MFMA q  +  ds_read of the next group's hi fragment q
+  //   round 2  lo.hi MFMA q  +  ds_read of the next group's lo fragment q
+  //   round 3  hi.lo MFMA q  +  LDS-DMA piece q of the next chunk
+  // Fragment q is thus requested 12 (hi) / 16 (lo) MFMAs before its first use.  In the chunk's
+  // last group the publishing barrier sits after round 1 and rounds 2 / 3 carry the NEXT chunk's
+  // first fragment reads.
+  u4 nh[4], nl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    nh[q] = ah[q];
+    nl[q] = al[q];
+  }
+  if constexpr (cross) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this group's fragments, in one wait
+    GC_FENCE();
+#pragma unroll
+    for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
+    GC_FENCE();
+    dma_wait();
+    __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < cnt) acc[n0 + q] = mfma32h(ah[q], bl, acc[n0 + q]);
+      nh[q] = wb_next[q * 128];
+      GC_FENCE();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < cnt) acc[n0 + q] = mfma32h(al[q], bh, acc[n0 + q]);
+      nl[q] = wb_next[q * 128 + 64];
+      GC_FENCE();
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < cnt) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
+      if (q < cnt2 && !(GC_EXP & 2)) nh[q] = wb[(n0 + 4 + q) * 128];
+      GC_FENCE();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < cnt) acc[n0 + q] = mfma32h(ah[q], bl, acc[n0 + q]);
+      if (q < cnt2 && !(GC_EXP & 2)) nl[q] = wb[(n0 + 4 + q) * 128 + 64];
+      GC_FENCE();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < cnt) acc[n0 + q] = mfma32h(al[q], bh, acc[n0 + q]);
+      if (!(GC_EXP & 1) && q < kPpg && T * kPpg + q < PIECES)
+        stage_piece(next_src, next_dst, T * kPpg + q, wave, lane);
+      GC_FENCE();
+    }
+  }
+#else
 #pragma unroll
   for (int p = 0; p < kPpg; ++p) {
     if (!(GC_EXP & 1) && T * kPpg + p < PIECES) stage_piece(next_src, next_dst, T * kPpg + p, wave, lane);
   }
-#if GC_SCHED_PIN
-  __builtin_amdgcn_sched_barrier(0);
-#endif
+  GC_FENCE();
   u4 nh[4], nl[4];
   // With the DMA out of the compiler's sight (GC_DMA_ASM) the next group's fragments are
   // requested BEFORE this group's MFMAs and stay in flight behind all twelve of them
@@ -308,26 +369,17 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
         nl[q] = al[q];
       }
     }
-    // one explicit wait for everything OLDER than the reads just issued (this group's fragments,
-    // requested 12 MFMAs ago): the compiler then has nothing left to wait for between the MFMAs
-    // (it would otherwise drip s_waitcnt lgkmcnt(14..8) in between them)
     constexpr int kInFlight = 2 * cnt2;
     __builtin_amdgcn_s_waitcnt(0xC07F | (kInFlight << 8));    // vmcnt(63) expcnt(7) lgkmcnt(kInFlight)
-#if GC_SCHED_PIN
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    GC_FENCE();
   }
   if constexpr (GC_DMA_ASM && !early) {
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this group's fragments, in one wait
-#if GC_SCHED_PIN
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    GC_FENCE();
   }
 #pragma unroll
   for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
-#if GC_SCHED_PIN
-  __builtin_amdgcn_sched_barrier(0);
-#endif
+  GC_FENCE();
   if constexpr (cross) {
     dma_wait();
     __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
@@ -348,15 +400,12 @@ __device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const 
       }
     }
   }
-#if GC_SCHED_PIN
-  __builtin_amdgcn_sched_barrier(0);
-#endif
+  GC_FENCE();
 #pragma unroll
   for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bl, acc[n0 + q]);
 #pragma unroll
   for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(al[q], bh, acc[n0 + q]);
-#if GC_SCHED_PIN
-  __builtin_amdgcn_sched_barrier(0);
+  GC_FENCE();
 #endif
   if constexpr (more) {
     mma16_group<NBLK, PIECES, T + 1, NEXT>(acc, wb, wb_next, nh, nl, oh, ol, bh, bl, next_src,

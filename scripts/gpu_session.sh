@@ -27,7 +27,11 @@ if [ $RC -ne 0 ]; then
 fi
 
 echo "== bench" | tee -a "$OUT/summary.txt"
+# sample power / clocks while the bench runs (is the chip power-limited under this kernel?)
+( for i in $(seq 1 40); do sleep 2; rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|Temperature \(Sensor junction" | tr '\n' ' '; echo; done ) > "$OUT/smi_during_bench.txt" 2>&1 &
+SMI_PID=$!
 timeout 1500 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
+kill $SMI_PID 2>/dev/null
 echo "bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "$OUT/summary.txt"; tail -5 "$OUT/bench.err" | tee -a "$OUT/summary.txt"
 
 if [ "${DO_F32:-0}" = "1" ]; then

@@ -124,8 +124,7 @@ def main():
 
   shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, linear_grid=linear_grid, node_grid=node_grid)
   builds = [("pipe2", ["-DGC_PIPE=2"]), ("pipe2_dma_builtin", ["-DGC_PIPE=2", "-DGC_DMA_ASM=0"]),
-            ("pipe2_lead3", ["-DGC_PIPE=2", "-DGC_DMA_LEAD=3"]), ("pipe2_lead4", ["-DGC_PIPE=2", "-DGC_DMA_LEAD=4"]),
-            ("pipe2_lead1", ["-DGC_PIPE=2", "-DGC_DMA_LEAD=1"]),
+            ("pipe2_noride", ["-DGC_PIPE=2", "-DGC_RIDE=0"]),
             ("pipe1", ["-DGC_PIPE=1"]),
             ("pipe2_nodma", ["-DGC_PIPE=2", "-DGC_EXP=1"]),
             ("pipe2_noreads", ["-DGC_PIPE=2", "-DGC_EXP=2"]),

@@ -23,6 +23,8 @@ __device__ __forceinline__ f4 mm32(float a, float b, f4 c) {
 // MODE 4: fp32 16x16x4 reference: 32 accumulators round robin
 // MODE 5/6/7: MODE 0 with 1 / 2 / 3 independent VALU ops (v_fma) wedged after EVERY MFMA
 // MODE 8: MODE 0 with one transcendental (v_exp) + one v_fma after every second MFMA
+// MODE 9: MODE 3's LDS fragment traffic, but ONE ds_read_b128 behind each of the first 8 MFMAs of a
+//         group (hi fragments first) instead of a burst of 8 in front of the MFMAs
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k(const u4* __restrict__ src, f4* out, long long* cyc, int iters) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -65,6 +67,31 @@ __global__ __launch_bounds__(256, 1) void k(const u4* __restrict__ src, f4* out,
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[4 * T + q] = mm(al[q], bh, acc[4 * T + q]);
         }
+      }
+    } else if (MODE == 9) {
+#pragma unroll
+      for (int T = 0; T < 8; ++T) {
+        u4 nh[4], nl[4];
+        const u4* base = lds + ((T + 1) & 7) * 512 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[4 * T + q] = mm(ah[q], bh, acc[4 * T + q]);
+          nh[q] = base[q * 128];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[4 * T + q] = mm(ah[q], bl, acc[4 * T + q]);
+          nl[q] = base[q * 128 + 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[4 * T + q] = mm(al[q], bh, acc[4 * T + q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ah[q] = nh[q]; al[q] = nl[q]; }
       }
     } else if (MODE >= 5 && MODE <= 8) {
       float va = __builtin_bit_cast(float, bh.x), vb = __builtin_bit_cast(float, bl.x);
@@ -160,6 +187,7 @@ int main() {
     run<6>("f16 g4 + 2 VALU after each MFMA", blocks, src, out, cyc);
     run<7>("f16 g4 + 3 VALU after each MFMA", blocks, src, out, cyc);
     run<8>("f16 g4 + exp,fma per 2 MFMA", blocks, src, out, cyc);
+    run<9>("f16 g4 + 1 ds_read behind each MFMA", blocks, src, out, cyc);
   }
   return 0;
 }
