@@ -27,12 +27,18 @@ if [ $RC -ne 0 ]; then
 fi
 
 echo "== bench" | tee -a "$OUT/summary.txt"
-# sample power / clocks while the bench runs (is the chip power-limited under this kernel?)
-( for i in $(seq 1 40); do sleep 2; rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|Temperature \(Sensor junction" | tr '\n' ' '; echo; done ) > "$OUT/smi_during_bench.txt" 2>&1 &
-SMI_PID=$!
 timeout 1500 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
-kill $SMI_PID 2>/dev/null
 echo "bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "$OUT/summary.txt"; tail -5 "$OUT/bench.err" | tee -a "$OUT/summary.txt"
+
+if [ "${DO_SMI:-0}" = "1" ]; then
+  # power / clocks under ~15 s of back-to-back steps (is the chip power-limited under this kernel?)
+  echo "== rocm-smi under load" | tee -a "$OUT/summary.txt"
+  ( for i in $(seq 1 60); do sleep 1; rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | tr '\n' ' '; echo; done ) > "$OUT/smi_under_load.txt" 2>&1 &
+  SMI_PID=$!
+  timeout 600 python bench.py --steps 200 --warmup 1 --no-cpu-baseline --no-cross-check > "$OUT/bench_200.json" 2> "$OUT/bench_200.err"
+  kill $SMI_PID 2>/dev/null
+  sort "$OUT/smi_under_load.txt" | uniq -c | sort -rn | head -6 | cut -c1-200 | tee -a "$OUT/summary.txt"
+fi
 
 if [ "${DO_F32:-0}" = "1" ]; then
   echo "== bench (exact fp32 MFMA mode)" | tee -a "$OUT/summary.txt"
