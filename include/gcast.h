@@ -57,7 +57,7 @@ extern "C" {
 #define GC_ELAUNCH (-2)
 
 /* Arithmetic of the two GEMMs of a launch.  Inputs, outputs, accumulation, bias,
- * LayerNorm, residual and segment-sum are fp32 in both modes.
+ * LayerNorm, residual and segment-sum are fp32 in every mode.
  *   GC_PREC_F32   v_mfma_f32_16x16x4_f32: exact fp32 products (157 TF peak).
  *   GC_PREC_F16X3 each fp32 operand x is split in registers into two halves
  *                 x = hi + lo (22 mantissa bits) and every product is formed as
