@@ -49,7 +49,8 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #endif                   // (launches without segment-sum; scripts/kernel_probe.py)
 #ifndef GC_EXP
 #define GC_EXP 0         // profiling experiments ONLY (scripts/kernel_probe.py; results are wrong):
-#endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA
+#endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA,
+                         // bit3 never wait for the DMA
 
 namespace {
 
@@ -100,7 +101,7 @@ __device__ __forceinline__ void stage_piece(const float* __restrict__ gsrc, floa
 // All LDS-DMA this wave has issued has landed (a no-op for the builtin path, where the barrier's
 // own fence waits).
 __device__ __forceinline__ void dma_wait() {
-#if GC_DMA_ASM
+#if GC_DMA_ASM && !(GC_EXP & 8)       // (GC_EXP bit3: profiling only -- never wait for the DMA)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
