@@ -90,3 +90,23 @@ def test_full_size_graph_fingerprints(full, golden_dir):
   for name, key in (("grid_node_feat", "grid_node_feat"), ("mesh_node_feat", "mesh_node_feat")):
     a = np.asarray(g[key], np.float64)
     assert abs(np.abs(a).sum() - want[name]["abs_sum_f64"]) <= 1e-6 * want[name]["abs_sum_f64"], name
+
+
+def test_config0_1deg_13level_step_matches_oracle():
+  """BASELINE.json configs[0] -- GraphCast_small-like 1 deg / 13 levels / M5, 16 processor steps
+  (65,160 grid nodes, 10,242 mesh nodes): the largest case the float64 oracle finishes in about a
+  minute on the GPU box's host cores.  rel-RMSE <= 2e-5 (budget 1e-4)."""
+  from oracle import graphcast as ogc
+  res, mesh_size, steps = 1.0, 5, 16
+  lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=steps,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
+  params = gparams.random_params(c_in, c_out, 512, steps)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(lat, lon)
+  x = np.random.default_rng(2).standard_normal((len(lat) * len(lon), 1, c_in)).astype(np.float32)
+  y = model.forward_grid_node_features(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+  want = ogc.forward(params, ogc.build_graphs(lat, lon, mesh_size), x, steps=steps, dtype=np.float64)
+  err = float(np.linalg.norm(y - want) / np.linalg.norm(want))
+  print(f"1 deg / 13 levels / M5 / 16 steps: rel-RMSE vs float64 oracle {err:.2e}")
+  assert err <= 2e-5
