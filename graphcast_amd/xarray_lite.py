@@ -367,6 +367,9 @@ class DataArray:
   def copy(self, deep=True):
     return DataArray(self._variable.copy(deep), coords=dict(self._coords), name=self.name)
 
+  def rename(self, new_name):
+    return DataArray(self._variable, coords=dict(self._coords), name=new_name)
+
   def compute(self):
     return self
 
@@ -602,6 +605,25 @@ def concat(objs: Sequence, dim: str, data_vars: str = "all", compat: str = "equa
     else:
       new_coords[k] = have[0]
   return Dataset._construct(new_vars, new_coords)
+
+
+def merge(objects: Sequence, compat: str = "no_conflicts", join: str = "outer", **_):
+  """xarray.merge for named DataArrays / Datasets whose shared coordinates are identical
+  (``join="exact"``: anything else raises, like xarray)."""
+  data_vars, coords = {}, {}
+  for o in objects:
+    items = ({o.name: o} if isinstance(o, DataArray) else {k: o[k] for k in o.keys()})
+    if isinstance(o, DataArray) and o.name is None:
+      raise ValueError("cannot merge an unnamed DataArray")
+    for k, da in items.items():
+      for ck, cv in da._coords.items():
+        if ck in coords and compat != "override" and not coords[ck].equals(cv):
+          raise ValueError(f"conflicting values for coordinate {ck!r}")
+        if ck in coords and coords[ck].shape != cv.shape:
+          raise ValueError(f"cannot align objects with join='exact' along {ck!r}")
+        coords.setdefault(ck, cv)
+      data_vars[k] = da.variable
+  return Dataset._construct(data_vars, coords)
 
 
 def zeros_like(obj, dtype=None):

@@ -40,6 +40,11 @@ Pinning status
   un-vendored, un-pinned dependencies (reference ``setup.py:37,42,43``) that
   are not installable here; their published algorithms are restated in
   ``gnn.py`` and cross-checked against torch's independent implementations.
+* HOST PLUMBING (Dataset <-> channels stacking, rollout window, normalisation wrapper):
+  PINNED by executing the reference's ``rollout.py`` / ``normalization.py`` /
+  ``xarray_tree.py`` / ``model_utils.py`` unmodified (``tests/golden/make_golden_rollout.py``
+  -> ``tests/golden/rollout_ref.npz``); ``oracle/stacking.py`` is an additional
+  container-free restatement.
 * mesh2grid containing-triangle query: the reference calls
   ``trimesh.nearest.on_surface`` (trimesh absent, un-pinned,
   ``setup.py:48``); restated from its published algorithm in

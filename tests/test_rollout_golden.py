@@ -1,0 +1,65 @@
+"""The host-side plumbing against the REFERENCE'S OWN CODE: tests/golden/rollout_ref.npz was
+produced by executing weathernext/utils/rollout.py (chunked_prediction), normalization.py
+(InputsAndResiduals), xarray_tree.py and model_utils.py (stacking helpers) unmodified
+(tests/golden/make_golden_rollout.py) around a fixed toy one-step predictor.  graphcast_amd's
+rollout / normalization / model_utils must reproduce those arrays: variable order, channel
+order, rolling window, residual + normalisation algebra, time coordinates."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from graphcast_amd import graphcast as gc
+from graphcast_amd import model_utils
+from graphcast_amd import normalization
+from graphcast_amd import predictor_base
+from graphcast_amd import rollout
+from graphcast_amd import synthetic
+from graphcast_amd import xarray_lite as xarray
+
+LAT = np.arange(-90, 91, 30.0)
+LON = np.arange(0, 360, 45.0)
+TASK = dataclasses.replace(gc.TASK_13, pressure_levels=(500, 850, 1000))
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+  return np.load(os.path.join(golden_dir, "rollout_ref.npz"))
+
+
+class Toy(predictor_base.Predictor):
+  """Same fixed linear map + tanh as make_golden_rollout.RefToy, on OUR stacking helpers."""
+
+  def __init__(self, w_seed):
+    self.w_seed, self.a, self.first = w_seed, None, None
+
+  def __call__(self, inputs, targets_template, forcings, **kw):
+    x = xarray.concat([model_utils.dataset_to_stacked(inputs),
+                       model_utils.dataset_to_stacked(forcings)], dim="channels")
+    data = np.asarray(model_utils.lat_lon_to_leading_axes(x).data, np.float32)
+    if self.a is None:
+      c_out = model_utils.dataset_to_stacked(targets_template).sizes["channels"]
+      self.a = (np.random.default_rng(self.w_seed).standard_normal((data.shape[-1], c_out))
+                / np.sqrt(data.shape[-1])).astype(np.float32)
+      self.first = data.copy()
+    y = xarray.DataArray(np.tanh(data @ self.a), dims=("lat", "lon", "batch", "channels"))
+    return model_utils.stacked_to_dataset(model_utils.restore_leading_axes(y).variable, targets_template)
+
+
+def test_rollout_normalisation_stacking_match_reference_execution(ref):
+  steps, seed, stats_seed, w_seed = (int(v) for v in ref["config"])
+  inputs, template, forcings = synthetic.make_example(TASK, LAT, LON, num_target_steps=steps, seed=seed)
+  mean, std, dstd = synthetic.make_stats(TASK, seed=stats_seed)
+  toy = Toy(w_seed)
+  wrapped = normalization.InputsAndResiduals(toy, std, mean, dstd)
+  preds = rollout.chunked_prediction(lambda rng, **kw: wrapped(**kw), None, inputs, template, forcings)
+  # the stacked, normalised input of the very first step: channel order + normalisation
+  np.testing.assert_array_equal(toy.first, ref["first_stacked_input"])
+  names = sorted(k[5:] for k in ref.files if k.startswith("pred:"))
+  assert names == sorted(preds.keys())
+  for k in names:
+    assert "|".join(preds[k].dims) == str(ref[f"dims:{k}"])
+    np.testing.assert_allclose(preds[k].values, ref[f"pred:{k}"], rtol=1e-6, atol=1e-6, err_msg=k)
+  got_time = np.asarray(preds.coords["time"].values).astype("timedelta64[ns]").astype(np.int64)
+  np.testing.assert_array_equal(got_time, ref["time"])
