@@ -434,3 +434,16 @@ def test_stacking_matches_container_free_oracle():
                                           len(LAT), len(LON))
   for k in template.keys():
     np.testing.assert_array_equal(ds[k].values, ref[k])
+
+
+def test_checkpoint_written_by_the_reference_loads(golden_dir):
+  """tests/golden/checkpoint_ref.npz was written by the reference's own checkpoint.dump
+  (make_golden_checkpoint.py, which also verified reference.load(our dump))."""
+  import os
+  with open(os.path.join(golden_dir, "checkpoint_ref.npz"), "rb") as f:
+    ck = checkpoint.load(f, gc.CheckPoint)
+  assert ck.model_config == gc.ModelConfig(1.0, 5, 512, 16, 1, 0.6)
+  assert ck.task_config.pressure_levels == (50, 100, 1000) and ck.task_config.input_variables == ("a", "b")
+  assert ck.description == "golden"
+  w = ck.params["grid2mesh_gnn/~_networks_builder/encoder_edges_grid2mesh_mlp/~/linear_0"]["w"]
+  np.testing.assert_array_equal(w, np.random.default_rng(0).standard_normal((4, 8)).astype(np.float32))
