@@ -75,6 +75,10 @@ class Predictor(predictor_base.Predictor):
       inputs = self._update_inputs(inputs, next_frame)
       per_step.append(predictions)
     out = xarray.concat(per_step, dim="time")
+    # the reference's scan stacks the per-step predictions along a NEW LEADING axis (:210-221):
+    # every predicted variable comes back as (time, batch, ...)
+    out = xarray.Dataset._construct({k: v.transpose("time", ...) for k, v in out._vars.items()},
+                                    out._coords)
     return out.assign_coords({k: v.variable for k, v in targets_template.coords.items()
                               if "time" in v.dims})
 

@@ -63,3 +63,17 @@ def test_rollout_normalisation_stacking_match_reference_execution(ref):
     np.testing.assert_allclose(preds[k].values, ref[f"pred:{k}"], rtol=1e-6, atol=1e-6, err_msg=k)
   got_time = np.asarray(preds.coords["time"].values).astype("timedelta64[ns]").astype(np.int64)
   np.testing.assert_array_equal(got_time, ref["time"])
+
+
+def test_autoregressive_predictor_matches_reference_execution(golden_dir):
+  """tests/golden/autoregressive_ref.npz = the reference's autoregressive.Predictor.__call__
+  (utils/autoregressive.py:127-222, hk.scan as a python loop) around the same toy step."""
+  from graphcast_amd import autoregressive
+  z = np.load(os.path.join(golden_dir, "autoregressive_ref.npz"))
+  steps, seed, w_seed = (int(v) for v in z["config"])
+  inputs, template, forcings = synthetic.make_example(TASK, LAT, LON, num_target_steps=steps, seed=seed)
+  strip = lambda ds: ds.drop_vars(["datetime"])
+  preds = autoregressive.Predictor(Toy(w_seed))(strip(inputs), strip(template), strip(forcings))
+  for k in sorted(k[5:] for k in z.files if k.startswith("pred:")):
+    assert "|".join(preds[k].dims) == str(z[f"dims:{k}"]), k       # time-leading, like hk.scan's stacking
+    np.testing.assert_allclose(preds[k].values, z[f"pred:{k}"], rtol=1e-6, atol=1e-6, err_msg=k)
