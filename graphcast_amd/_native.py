@@ -16,6 +16,7 @@ MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
 OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
+LAYOUT_CHUNKED, LAYOUT_COLOWN = 0, 1
 LATENT = 512
 TILE_ROWS = 64
 K_CHUNK = 32
@@ -27,7 +28,7 @@ class RowMlpDesc(ctypes.Structure):
   """struct gc_rowmlp_desc (include/gcast.h) -- field order must match exactly."""
   _fields_ = [
       ("mode", ctypes.c_int), ("prec", ctypes.c_int), ("n_rows", ctypes.c_int),
-      ("reserved0", ctypes.c_int), ("w1_scale", ctypes.c_float), ("w2_scale", ctypes.c_float),
+      ("layout", ctypes.c_int), ("w1_scale", ctypes.c_float), ("w2_scale", ctypes.c_float),
       ("a0", _fp), ("lda0", ctypes.c_int), ("k0", ctypes.c_int),
       ("a1", _fp), ("lda1", ctypes.c_int), ("k1", ctypes.c_int),
       ("w1p", _fp),
@@ -87,7 +88,8 @@ def build(force=False, verbose=False):
   """Compiles csrc/gcast.hip for gfx950 with hipcc (all build variants)."""
   src = os.path.join(_CSRC, "gcast.hip")
   hdr = os.path.join(_INCLUDE, "gcast.h")
-  newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+  deps = [src, hdr] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".inc")]
+  newest = max(os.path.getmtime(f) for f in deps)
   for variant, (_, define) in VARIANTS.items():
     out = library_path(variant)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:

@@ -946,6 +946,8 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
 #endif
 }
 
+#include "rowmlp_colown.inc"
+
 // ---- GC_PREC_BF16 -----------------------------------------------------------------------
 // The tier the published GraphCast demo runs (casting.Bfloat16Cast, utils/casting.py:31-65): GEMM
 // operands rounded to bfloat16 (round to nearest even), ONE v_mfma_f32_16x16x32_bf16 per product,
@@ -1336,6 +1338,23 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlp_kernel");
 }
 
+bool g_co_attr_set = false;
+
+int launch_rowmlp_colown(const gc_rowmlp_desc& d, hipStream_t s) {
+  if (!g_co_attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpc_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kCoLdsBytes);
+    if (e != hipSuccess) {
+      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%d): %s", kCoLdsBytes, hipGetErrorString(e));
+      return GC_ELAUNCH;
+    }
+    g_co_attr_set = true;
+  }
+  const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
+  hipLaunchKernelGGL(rowmlpc_kernel, dim3(tiles), dim3(256), kCoLdsBytes, s, d);
+  return check_launch("rowmlpc_kernel");
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1361,7 +1380,14 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
   if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16)
     return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
-  if (d.reserved0 != 0) return fail(GC_EINVAL, "gc_rowmlp: reserved0 must be 0");
+  if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_COLOWN)
+    return fail(GC_EINVAL, "gc_rowmlp: unknown weight layout");
+  if (d.layout == GC_LAYOUT_COLOWN) {
+    if (d.prec != GC_PREC_F16X3 || d.mode != GC_MODE_MLP_LN)
+      return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_COLOWN is built for GC_PREC_F16X3 + GC_MODE_MLP_LN only");
+    if (d.k0 > 512 || (d.k1 != 0 && (d.k0 != 512 || d.k1 != 512)))
+      return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_COLOWN needs k0 <= 512 and k1 in {0, 512} (k1 only with k0 == 512)");
+  }
   if ((d.k0 | d.k1) & 31 || d.k0 < 0 || d.k1 < 0) return fail(GC_EINVAL, "gc_rowmlp: k0/k1 must be multiples of 32");
   if (d.k0 == 0 && d.k1 != 0) return fail(GC_EINVAL, "gc_rowmlp: k1 without k0");
   if (d.k0 + d.k1 > 0 && (!d.a0 || !d.w1p)) return fail(GC_EINVAL, "gc_rowmlp: layer-1 GEMM needs a0 and w1p");
@@ -1390,6 +1416,7 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
       } else if (!d.out) {
         return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg)");
       }
+      if (d.layout == GC_LAYOUT_COLOWN) return launch_rowmlp_colown(d, s);
       return launch_rowmlp<GC_MODE_MLP_LN>(d, s);
     case GC_MODE_MLP_OUT:
       if (!d.w2p || !d.b2 || d.n2 <= 0 || d.n2 > 240 || !d.out) return fail(GC_EINVAL, "gc_rowmlp MLP_OUT: needs w2p, b2, out, 0 < n2 <= 240");
@@ -1506,7 +1533,7 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR2(x) #x
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
-  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;pipe=" GC_STR(GC_PIPE);
+  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|3xf16_32x32x16(colown)|bf16_16x16x32;pipe=" GC_STR(GC_PIPE);
 }
 
 }  // extern "C"

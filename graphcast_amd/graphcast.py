@@ -98,7 +98,7 @@ class GraphCast(predictor_base.Predictor):
 
   def __init__(self, model_config: ModelConfig, task_config: TaskConfig,
                params: Optional[Mapping[str, Mapping[str, Any]]] = None, device: str = "cuda:0",
-               precision: Optional[str] = None):
+               precision: Optional[str] = None, colown: Optional[bool] = None):
     if model_config.hidden_layers != 1:
       raise NotImplementedError("the MI355X build fuses exactly one hidden layer per MLP "
                                 "(hidden_layers=1, the value of every published GraphCast)")
@@ -108,6 +108,7 @@ class GraphCast(predictor_base.Predictor):
     self._task_config = task_config
     self._device = device
     self._precision = precision       # None -> engine default / GCAST_PRECISION
+    self._colown = colown             # f16x3 only: column-owner MLP_LN kernels (None -> GCAST_COLOWN, default off)
     self._spatial_features_kwargs = dict(
         add_node_positions=False, add_node_latitude=True, add_node_longitude=True,
         add_relative_positions=True, relative_longitude_local_coordinates=True,
@@ -249,7 +250,8 @@ class GraphCast(predictor_base.Predictor):
       from graphcast_amd import engine      # needs the HIP library; fails loudly without it
       self._engine = engine.StepEngine(
           self.graph_arrays(), self._params, num_steps=self._model_config.gnn_msg_steps,
-          c_in=c_in, c_out=self._num_outputs, device=self._device, precision=self._precision)
+          c_in=c_in, c_out=self._num_outputs, device=self._device, precision=self._precision,
+          colown=self._colown)
     return self._engine
 
   def forward_grid_node_features(self, grid_node_features, out=None):

@@ -73,6 +73,21 @@ extern "C" {
  *                 [NP/16 n-blocks][64 lanes][8 bf16] per 32-row K chunk (NP * 64 bytes). */
 enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16 = 2 };
 
+/* How w1p / w2p are packed, i.e. which tile formulation runs.
+ *   GC_LAYOUT_CHUNKED  the layouts described above: 32-row K chunks staged through LDS, every wave
+ *                      owns 16 rows of the tile and reads the whole chunk (all modes, all precisions).
+ *   GC_LAYOUT_COLOWN   "column owner" (GC_PREC_F16X3 + GC_MODE_MLP_LN only): every wave owns 128
+ *                      output columns of the 64-row tile and streams its own weight fragments
+ *                      L2 -> registers; rows and hidden activations are shared through LDS; products
+ *                      are v_mfma_f32_32x32x16_f16.  A matrix [K, 512] (K zero-padded to a multiple
+ *                      of 512) is stored per K=16 step s as
+ *                        [s][wave 0..3][column block cb 0..3][hi, lo][lane 0..63][8 halves]   (32 KiB)
+ *                      where lane l = 32 g + n holds part(scale * W[16 s + 8 g + j][128 wave + 32 cb + n]),
+ *                      j = 0..7: one MFMA A fragment per 1 KiB, fetched with one coalesced
+ *                      global_load_dwordx4 per lane.  Same (hi, lo) split, same scales as above.
+ *                      Requires k0 <= 512 and k1 in {0, 512} (k1 > 0 only with k0 == 512). */
+enum gc_weight_layout { GC_LAYOUT_CHUNKED = 0, GC_LAYOUT_COLOWN = 1 };
+
 /* What a fused row-MLP launch produces. */
 enum gc_rowmlp_mode {
   /* out = A.W1 + addends            (no activation, no layer 2)            */
@@ -103,7 +118,7 @@ typedef struct gc_rowmlp_desc {
   int mode;                /* enum gc_rowmlp_mode */
   int prec;                /* enum gc_precision: selects the layout w1p / w2p are packed in */
   int n_rows;              /* rows to process */
-  int reserved0;           /* keeps the pointers below 8-byte aligned; must be 0 */
+  int layout;              /* enum gc_weight_layout: the packing of w1p / w2p */
   /* Power-of-two factors the packed weights were multiplied by (GC_PREC_F16X3: chosen at pack
    * time so that the lo halves of typical weights are NORMAL fp16 numbers; the kernel scales the
    * layer's addends by the same factor and the accumulators by its inverse -- all exact).

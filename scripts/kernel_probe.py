@@ -55,13 +55,21 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "probe.json"))
   ap.add_argument("--prec", default="f16x3")
+  ap.add_argument("--layout", default="chunked", choices=["chunked", "co"],
+                  help="co: MLP_LN shapes run the column-owner kernel (GC_LAYOUT_COLOWN); builds = CO_EXP variants")
   args = ap.parse_args()
   dev = torch.device("cuda:0")
   rng = np.random.default_rng(0)
   split = args.prec == "f16x3"
   up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
   w = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
-  if split:
+  co = args.layout == "co"
+  if co:
+    w1 = up(packing.pack_weight_split_co(w).view(np.int16))
+    w2 = up(packing.pack_weight_split_co(w).view(np.int16))
+    w1b = up(packing.pack_weight_split_co(np.concatenate([w, w])).view(np.int16))
+    w1lin = up(packing.pack_weight_split(w).view(np.int16))
+  elif split:
     w1 = up(packing.pack_weight_split(w).view(np.int16))
     w2 = up(packing.pack_weight_split(w, chained=True).view(np.int16))
     w1b = up(packing.pack_weight_split(np.concatenate([w, w])).view(np.int16))
@@ -87,6 +95,7 @@ def main():
   def desc(mode, n_rows):
     d = nat.RowMlpDesc()
     d.mode, d.n_rows, d.prec = mode, n_rows, prec
+    d.layout = nat.LAYOUT_COLOWN if (co and mode == nat.MODE_MLP_LN) else nat.LAYOUT_CHUNKED
     return d
 
   def proc_edge():
@@ -109,7 +118,7 @@ def main():
 
   def linear_grid():
     d = desc(nat.MODE_LINEAR, n_g)
-    d.a0, d.lda0, d.k0, d.w1p = hg.data_ptr(), D, D, w1.data_ptr()
+    d.a0, d.lda0, d.k0, d.w1p = hg.data_ptr(), D, D, (w1lin if co else w1).data_ptr()
     d.out, d.ldo = og.data_ptr(), D
     return d, 16, n_g
 
@@ -132,6 +141,58 @@ def main():
             ("pipe2_nomfma", ["-DGC_PIPE=2", "-DGC_EXP=4"]),
             ("pipe2_nodma_noreads", ["-DGC_PIPE=2", "-DGC_EXP=3"]),
             ("pipe2_nosched", ["-DGC_PIPE=2", "-DGC_SCHED_PIN=0"])]
+  if co:
+    builds = [("co", []), ("co_stg8", ["-DCO_STAGGER_US=8"]), ("co_stg15", ["-DCO_STAGGER_US=15"]),
+              ("co_stg22", ["-DCO_STAGGER_US=22"]), ("co_a3", ["-DCO_AHEAD=3"]), ("co_a4", ["-DCO_AHEAD=4"]), ("co_a5", ["-DCO_AHEAD=5"]),
+              ("co_stage_cached", ["-DCO_EXP=64"]), ("co_add_cached", ["-DCO_EXP=128"]),
+              ("co_all_cached_nostore", ["-DCO_EXP=208"]),
+              ("co_noadd", ["-DCO_EXP=1"]), ("co_nostage", ["-DCO_EXP=2"]),
+              ("co_noadd_nostage", ["-DCO_EXP=3"]), ("co_noweights", ["-DCO_EXP=4"]),
+              ("co_nomfma", ["-DCO_EXP=8"]), ("co_nostore", ["-DCO_EXP=16"]),
+              ("co_nohbm", ["-DCO_EXP=19"]), ("co_nohbm_nobarrier", ["-DCO_EXP=51"]),
+              ("co_noweights_nohbm", ["-DCO_EXP=23"])]
+    shapes.pop("linear_grid")
+  if co and os.environ.get("PROBE_TRACE"):
+    lib = build("cotrace", ["-DCO_TRACE=1"] + os.environ.get("PROBE_DEFINES", "").split())
+    out = {}
+    names = ["prologue", "layer1", "boundary", "layer2", "ln_stats", "ytile", "colpass", "segsum"]
+    for name in ("proc_edge", "gemm_only_mlp", "node_grid"):
+      d, chunks, rows = shapes[name]()
+      tiles = (rows + 63) // 64
+      if d.seg:      # trace behind the partial rows (CO_MARK)
+        buf = torch.zeros((2 * tiles * D + tiles * 32,), dtype=torch.float32, device=dev)
+        d.partial = buf.data_ptr()
+        ms = time_launch(lib, d, iters=1)
+        t = buf[2 * tiles * D:].view(torch.int64).view(tiles, 16).cpu().numpy()
+      else:
+        trace = torch.zeros((tiles, 16), dtype=torch.int64, device=dev)
+        d.partial = trace.data_ptr()
+        ms = time_launch(lib, d, iters=1)
+        t = trace.cpu().numpy()
+      ph = np.diff(t[:, :9], axis=1).astype(np.float64)
+      row = {"ms": round(ms, 4), "tiles": int(tiles), "total_ticks_mean": float((t[:, 8] - t[:, 0]).mean())}
+      for j, nme in enumerate(names):
+        row[nme + "_ticks_mean"] = round(float(ph[:, j].mean()), 1)
+      row["bulk_issue_to_landed"] = round(float((t[:, 10] - t[:, 9]).mean()), 1)
+      row["bulk_convert_write"] = round(float((t[:, 11] - t[:, 10]).mean()), 1)
+      row["bulk_barrier"] = round(float((t[:, 12] - t[:, 11]).mean()), 1)
+      gaps, per_cu = [], []
+      for cu in np.unique(t[:, 15]):
+        sel = t[t[:, 15] == cu]
+        sel = sel[np.argsort(sel[:, 13])]
+        gaps.extend((sel[1:, 13] - sel[:-1, 14]).tolist())
+        per_cu.append(len(sel))
+      row["wg_gap_us_mean"] = round(float(np.mean(gaps)) / 100.0, 2) if gaps else None
+      row["wg_us_mean"] = round(float((t[:, 14] - t[:, 13]).mean()) / 100.0, 2)
+      row["launch_span_us"] = round(float(t[:, 14].max() - t[:, 13].min()) / 100.0, 1)
+      row["tiles_per_cu_min_max"] = [int(min(per_cu)), int(max(per_cu))]
+      row["n_cus"] = len(per_cu)
+      row["start_to_bulk_issued"] = round(float((t[:, 9] - t[:, 0]).mean()), 1)
+      out[name] = row
+      print("cotrace", name, json.dumps(row), flush=True)
+    with open(args.out, "w") as f:
+      json.dump(out, f, indent=1)
+    return
   if os.environ.get("PROBE_TRACE"):
     # phase timeline of one wave per workgroup (GC_TRACE build): cycles per phase + dispatch gaps
     lib = build("trace", ["-DGC_PIPE=2", "-DGC_TRACE=1"])

@@ -25,13 +25,17 @@ REL_RMSE_TOL = {"f32": 2e-6, "f16x3": 3e-6, "bf16": 5e-5}
 MAX_ABS_TOLS = {"f32": 2e-4, "f16x3": 2e-4, "bf16": 2e-2}
 MAX_ABS_TOL = 2e-4
 _PREC = "f32"          # set per test by the autouse fixture below
+_CO = False            # "f16x3co": the MLP_LN launches run the column-owner formulation (GC_LAYOUT_COLOWN)
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "bf16"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3co", "bf16"])
 def prec(request):
-  global _PREC
-  _PREC = request.param
-  return request.param
+  global _PREC, _CO
+  _CO = request.param == "f16x3co"
+  _PREC = "f16x3" if _CO else request.param
+  if _CO and not any(k in request.node.name for k in ("mlp_ln", "edge_block")):
+    pytest.skip("the column-owner layout only exists for MLP_LN launches")
+  return _PREC
 
 
 class Image(np.ndarray):
@@ -46,7 +50,8 @@ def pw1(w):
   """Layer-1 weight image for the current arithmetic mode."""
   if _PREC == "f16x3":
     sc = packing.choose_weight_scale(w)
-    img = packing.pack_weight_split(w, scale=sc).view(np.int16).view(Image)
+    pack = packing.pack_weight_split_co if _CO else packing.pack_weight_split
+    img = pack(w, scale=sc).view(np.int16).view(Image)
     img.scale = sc
     return img
   if _PREC == "bf16":
@@ -64,7 +69,10 @@ def pw2(w, np_cols=D):
   """Layer-2 weight image (chained K order in split mode)."""
   if _PREC == "f16x3":
     sc = packing.choose_weight_scale(w)
-    img = packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc).view(np.int16).view(Image)
+    if _CO:
+      img = packing.pack_weight_split_co(w, scale=sc).view(np.int16).view(Image)
+    else:
+      img = packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc).view(np.int16).view(Image)
     img.scale = sc
     return img
   if _PREC == "bf16":
@@ -80,6 +88,7 @@ def apply_scales(d):
 def new_desc(mode, n_rows):
   d = nat.RowMlpDesc()
   d.mode, d.n_rows, d.prec = mode, n_rows, nat.PRECISIONS[_PREC]
+  d.layout = nat.LAYOUT_COLOWN if (_CO and mode == nat.MODE_MLP_LN) else nat.LAYOUT_CHUNKED
   return d
 
 
