@@ -582,31 +582,46 @@ __device__ __forceinline__ void finish_rows(f4 (&o2)[kNB], const gc_rowmlp_desc&
     float sx = 0.f, sy = 0.f;
     int cur = -1;
     int run_start = 0;
-    for (int r = 0; r <= GC_TILE_ROWS; ++r) {
-      const int sid = r < GC_TILE_ROWS ? segs[r] : -2;
-      if (sid != cur) {
-        if (cur >= 0) {
-          float* dst;
-          if (run_start == 0 && (flags & 1)) {
-            dst = d.partial + (size_t)(2 * tile) * kD;
-          } else if (r == GC_TILE_ROWS && (flags & 2)) {
-            dst = d.partial + (size_t)(2 * tile + 1) * kD;
-          } else {
-            dst = d.agg + (size_t)cur * kD;
-          }
-          *reinterpret_cast<float2*>(dst + c2) = make_float2(sx, sy);
+    auto flush = [&](int r) {
+      if (cur >= 0) {
+        float* dst;
+        if (run_start == 0 && (flags & 1)) {
+          dst = d.partial + (size_t)(2 * tile) * kD;
+        } else if (r == GC_TILE_ROWS && (flags & 2)) {
+          dst = d.partial + (size_t)(2 * tile + 1) * kD;
+        } else {
+          dst = d.agg + (size_t)cur * kD;
         }
-        cur = sid;
-        run_start = r;
-        sx = 0.f;
-        sy = 0.f;
+        *reinterpret_cast<float2*>(dst + c2) = make_float2(sx, sy);
       }
-      if (sid >= 0) {
-        const float2 v = *reinterpret_cast<const float2*>(ytile + r * kYld + c2);
-        sx += v.x;
-        sy += v.y;
+    };
+#pragma unroll 1
+    for (int r0 = 0; r0 < GC_TILE_ROWS; r0 += 8) {
+      // eight rows per trip: ids (two broadcast reads) and values up front -- one LDS latency per
+      // eight rows instead of one per row -- then pure VALU / branch logic, rows in order
+      const int4 s0 = *reinterpret_cast<const int4*>(segs + r0);
+      const int4 s1 = *reinterpret_cast<const int4*>(segs + r0 + 4);
+      const int sg[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      float2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(ytile + (r0 + k) * kYld + c2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int sid = sg[k];
+        if (sid != cur) {
+          flush(r0 + k);
+          cur = sid;
+          run_start = r0 + k;
+          sx = 0.f;
+          sy = 0.f;
+        }
+        if (sid >= 0) {
+          sx += v[k].x;
+          sy += v[k].y;
+        }
       }
     }
+    flush(GC_TILE_ROWS);
   }
 }
 
