@@ -57,6 +57,25 @@ class Op(ctypes.Structure):
   ]
 
 
+class EdgeSet(ctypes.Structure):
+  """struct gc_edge_set (host pointers)."""
+  _fields_ = [("n_edges", ctypes.c_int), ("h_senders", _fp), ("h_receivers", _fp), ("h_feat", _fp),
+              ("n_feat", ctypes.c_int)]
+
+
+class ModelDesc(ctypes.Structure):
+  """struct gc_model_desc."""
+  _fields_ = [("n_grid", ctypes.c_int), ("n_mesh", ctypes.c_int), ("c_in", ctypes.c_int),
+              ("c_out", ctypes.c_int), ("n_struct", ctypes.c_int), ("num_steps", ctypes.c_int),
+              ("prec", ctypes.c_int), ("h_grid_node_feat", _fp), ("h_mesh_node_feat", _fp),
+              ("g2m", EdgeSet), ("mesh", EdgeSet), ("m2g", EdgeSet)]
+
+
+class TensorDesc(ctypes.Structure):
+  """struct gc_tensor_desc."""
+  _fields_ = [("name", ctypes.c_char_p), ("h_data", _fp), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
+
+
 class AdvanceDesc(ctypes.Structure):
   """struct gc_advance_desc."""
   _fields_ = [
@@ -70,7 +89,8 @@ class AdvanceDesc(ctypes.Structure):
   ]
 
 
-EXPORTS = ("gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
+EXPORTS = ("gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_plan_destroy",
+           "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
 
@@ -129,6 +149,21 @@ def lib():
     for name in ("gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
                  "gc_run_program", "gc_time_program"):
       getattr(l, name).restype = ctypes.c_int
+    l.gc_plan_create.argtypes = [ctypes.POINTER(ModelDesc), ctypes.POINTER(TensorDesc), ctypes.c_int,
+                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    l.gc_plan_create.restype = ctypes.c_int
+    l.gc_plan_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    l.gc_plan_workspace_bytes.restype = ctypes.c_size_t
+    l.gc_step_forward.argtypes = [ctypes.c_void_p, _fp, _fp, ctypes.c_int, _fp, ctypes.c_size_t, ctypes.c_void_p]
+    l.gc_step_forward.restype = ctypes.c_int
+    l.gc_plan_destroy.argtypes = [ctypes.c_void_p]
+    l.gc_plan_destroy.restype = None
+    l.gc_host_pack_weight.argtypes = [ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      _fp, ctypes.POINTER(ctypes.c_float)]
+    l.gc_host_pack_weight.restype = ctypes.c_size_t
+    l.gc_host_pack_edges.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_int] + [_fp] * 5 + [
+        ctypes.POINTER(ctypes.c_int), _fp, ctypes.POINTER(ctypes.c_int)]
+    l.gc_host_pack_edges.restype = ctypes.c_int
     l.gc_last_error.restype = ctypes.c_char_p
     l.gc_abi_sizeof.argtypes = [ctypes.c_int]
     l.gc_abi_sizeof.restype = ctypes.c_size_t

@@ -1545,6 +1545,8 @@ size_t gc_abi_sizeof(int what) {
 
 const char* gc_last_error(void) { return g_err; }
 
+#include "gcast_plan.inc"
+
 #define GC_STR2(x) #x
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {

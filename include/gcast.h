@@ -225,6 +225,75 @@ int gc_run_program(const gc_op* h_ops, int n_ops, void* stream);
  * Synchronises the stream.  Not used on the product path. */
 int gc_time_program(const gc_op* h_ops, int n_ops, int iters, float* h_ms, void* stream);
 
+/* ---- Plan API: the whole step behind two calls, for hosts without the Python packer ------------
+ * A plan owns the static device data of one model on one device: the three edge sets in packed
+ * (receiver-sorted, tile-packed) order, the packed weights of every MLP in the chosen arithmetic,
+ * and the input-independent terms folded at creation.  It replaces what the
+ * reference builds in GraphCast.__init__ / _maybe_init (graphcast.py:184-292,368-548) plus the
+ * haiku parameter tree of a CheckPoint (graphcast.py:145-151).  All pointers in the descriptors
+ * below are HOST pointers; arrays are in the reference's own order (edges in construction order,
+ * weights as haiku stores them: w [in, out], row-major).
+ *
+ * gc_plan_create   packs on the host, uploads, runs the folding launches on `stream` and
+ *                  synchronises it once (creation is not on the hot path).  Device memory of the
+ *                  plan is allocated with hipMalloc and released by gc_plan_destroy.
+ * gc_step_forward  x [n_grid, batch, c_in] -> y [n_grid, batch, c_out] (device, fp32, contiguous):
+ *                  enqueues the launches of graphcast.py:311-319 on `stream`; never allocates,
+ *                  never synchronises.  `workspace` (device, 256-byte aligned,
+ *                  >= gc_plan_workspace_bytes) belongs to the caller; one workspace per stream in
+ *                  flight -- the plan itself is immutable after creation.
+ * Tensor names are "<haiku module>/<leaf>", e.g.
+ *   "mesh_gnn/~_networks_builder/processor_edges_3_mesh_mlp/~/linear_0/w"
+ *   "grid2mesh_gnn/~_networks_builder/encoder_nodes_grid_nodes_layer_norm/scale"  */
+typedef struct gc_plan gc_plan;
+
+typedef struct gc_edge_set {
+  int n_edges;
+  const int* h_senders;      /* [n_edges] */
+  const int* h_receivers;    /* [n_edges] */
+  const float* h_feat;       /* [n_edges, n_feat] structural edge features */
+  int n_feat;                /* <= 32 */
+} gc_edge_set;
+
+typedef struct gc_model_desc {
+  int n_grid, n_mesh;
+  int c_in, c_out;           /* channels of x / y (structural node features not included) */
+  int n_struct;              /* structural node features per node (3) */
+  int num_steps;             /* processor message-passing steps (16) */
+  int prec;                  /* enum gc_precision */
+  const float* h_grid_node_feat;   /* [n_grid, n_struct] */
+  const float* h_mesh_node_feat;   /* [n_mesh, n_struct] */
+  gc_edge_set g2m, mesh, m2g;      /* grid->mesh, mesh->mesh, mesh->grid */
+} gc_model_desc;
+
+typedef struct gc_tensor_desc {
+  const char* name;
+  const float* h_data;       /* row-major [rows, cols]; vectors: rows == 1 */
+  int rows, cols;
+} gc_tensor_desc;
+
+int gc_plan_create(const gc_model_desc* model, const gc_tensor_desc* tensors, int n_tensors,
+                   void* stream, gc_plan** out);
+size_t gc_plan_workspace_bytes(const gc_plan* plan, int batch);
+int gc_step_forward(const gc_plan* plan, const float* x, float* y, int batch, void* workspace,
+                    size_t workspace_bytes, void* stream);
+void gc_plan_destroy(gc_plan* plan);
+
+/* Host-side packers the plan uses, exported so that a binding can check them bit for bit
+ * against its own (tests/test_native_abi.py compares them with graphcast_amd/packing.py).
+ * gc_host_pack_weight: w [k, n] -> the image of `prec` (chunked layouts above); `chained` selects
+ *   the layer-2 K map; *scale_out receives the power of two chosen for GC_PREC_F16X3 (1 otherwise).
+ *   Returns the image size in bytes (also with h_out == NULL), 0 on bad arguments.
+ * gc_host_pack_edges: receiver-sorted tile packing; outputs (all optional) as documented for
+ *   gc_rowmlp_desc.seg / tile_flags and gc_seg_fixup; returns n_rows (multiple of 64), < 0 on error.
+ *   h_perm/h_snd/h_rcv need n_rows entries (<= 64 * ceil(n_edges / 21) is always enough),
+ *   h_flags n_rows / 64, h_fix 3 * n_fix (recv, t0, t1 interleaved per entry), h_empty n_empty. */
+size_t gc_host_pack_weight(int prec, int chained, const float* h_w, int k, int n, int np_cols,
+                           void* h_out, float* scale_out);
+int gc_host_pack_edges(int n_edges, const int* h_senders, const int* h_receivers, int n_receivers,
+                       long long* h_perm, int* h_snd, int* h_rcv, int* h_flags,
+                       int* h_fix, int* n_fix, int* h_empty, int* n_empty);
+
 /* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for 1, sizeof(gc_advance_desc) for 2, 0 otherwise:
  * lets a foreign-language binding verify its struct layout at load time. */
 size_t gc_abi_sizeof(int what);

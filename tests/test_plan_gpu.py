@@ -1,0 +1,63 @@
+"""The plan API of the C-ABI (gc_plan_create / gc_step_forward: C++ packers + C++ launch program)
+against the Python plan builder (engine.StepEngine) on the same graphs and weights: the two build
+the same images and enqueue the same launches, so the outputs must be IDENTICAL, bit for bit --
+and both are checked against the float64 oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from graphcast_amd import engine, plan            # noqa: E402
+from oracle import graphcast as ogc               # noqa: E402
+from oracle import params as oparams              # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def case():
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  res, mesh_size, steps = 4.0, 3, 2
+  lat = np.arange(-90, 90 + res / 2, res)
+  lon = np.arange(0, 360, res)
+  graphs = ogc.build_graphs(lat, lon, mesh_size)
+  c_in, c_out = 183, 83
+  params = oparams.init_params(c_in, c_out, 512, steps, seed=3, nontrivial=True)
+  return dict(graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16"])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_native_plan_equals_python_plan_bit_for_bit(case, precision, batch):
+  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"], precision=precision)
+  eng = engine.StepEngine(case["graphs"], case["params"], colown=False, **kw)
+  nat_plan = plan.NativePlan(case["graphs"], case["params"], **kw)
+  rng = np.random.default_rng(batch)
+  x = torch.from_numpy(rng.standard_normal((case["graphs"]["n_grid"], batch, case["c_in"])).astype(np.float32)).to("cuda:0")
+  want = eng(x)
+  got = nat_plan(x)
+  torch.cuda.synchronize()
+  assert torch.isfinite(got).all()
+  assert torch.equal(got, want)
+  again = nat_plan(x)                         # workspace reuse, determinism
+  torch.cuda.synchronize()
+  assert torch.equal(again, got)
+  if precision != "bf16" and batch == 1:
+    ref = ogc.forward(case["params"], case["graphs"], x.cpu().numpy(), steps=case["steps"], dtype=np.float64)
+    err = float(np.linalg.norm(got.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref))
+    print(f"native plan vs float64 oracle ({precision}): rel-RMSE {err:.2e}")
+    assert err <= 2e-5
+  nat_plan.close()
+
+
+def test_native_plan_rejects_bad_inputs(case):
+  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"])
+  bad = dict(case["params"])
+  bad.pop("mesh_gnn/~_networks_builder/processor_edges_1_mesh_mlp/~/linear_0")
+  with pytest.raises(Exception, match="missing tensor"):
+    plan.NativePlan(case["graphs"], bad, **kw)
+  p = plan.NativePlan(case["graphs"], case["params"], **kw)
+  with pytest.raises(ValueError):
+    p(torch.zeros((5, 1, case["c_in"]), device="cuda:0"))
+  p.close()

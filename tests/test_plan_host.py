@@ -1,0 +1,111 @@
+"""The C++ host packers behind the plan API (gc_host_pack_weight / gc_host_pack_edges,
+csrc/gcast_plan.inc) against the numpy packers of graphcast_amd/packing.py, bit for bit; and the
+plan API's argument checking.  No GPU needed: nothing here launches a kernel."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from graphcast_amd import _native as nat
+from graphcast_amd import packing
+
+
+@pytest.fixture(scope="module")
+def lib():
+  return nat.lib()
+
+
+@pytest.mark.parametrize("k,n,np_cols,chained", [(512, 512, 512, False), (474, 512, 512, False),
+                                                 (512, 227, 256, True), (4, 512, 512, False),
+                                                 (1024, 512, 512, False), (512, 512, 512, True)])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
+def test_host_pack_weight_equals_numpy_packer(lib, prec, k, n, np_cols, chained):
+  rng = np.random.default_rng(k + n)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  if prec == "f32":
+    if chained:
+      pytest.skip("the fp32 layout has one K order")
+    want, want_scale = packing.pack_weight(w, np_cols=np_cols), 1.0
+  elif prec == "f16x3":
+    want_scale = packing.choose_weight_scale(w)
+    want = packing.pack_weight_split(w, np_cols=np_cols, chained=chained, scale=want_scale)
+  else:
+    want, want_scale = packing.pack_weight_bf16(w, np_cols=np_cols, chained=chained), 1.0
+  scale = ctypes.c_float(0)
+  size = lib.gc_host_pack_weight(nat.PRECISIONS[prec], int(chained), w.ctypes.data, k, n, np_cols, None,
+                                 ctypes.byref(scale))
+  assert size == want.nbytes
+  got = np.empty(size, dtype=np.uint8)
+  assert lib.gc_host_pack_weight(nat.PRECISIONS[prec], int(chained), w.ctypes.data, k, n, np_cols,
+                                 got.ctypes.data, ctypes.byref(scale)) == size
+  assert scale.value == want_scale
+  np.testing.assert_array_equal(got, np.ascontiguousarray(want).view(np.uint8).ravel())
+
+
+def test_host_pack_weight_rejects_bad_arguments(lib):
+  w = np.zeros((8, 8), np.float32)
+  assert lib.gc_host_pack_weight(7, 0, w.ctypes.data, 8, 8, 512, None, None) == 0       # unknown precision
+  assert lib.gc_host_pack_weight(0, 0, w.ctypes.data, 8, 600, 512, None, None) == 0     # wider than the layout
+  # (huge weights are fine in split mode: the power-of-two scale keeps max |s w| <= 2^14)
+  big = np.full((8, 8), 1e6, np.float32)
+  scale = ctypes.c_float(0)
+  assert lib.gc_host_pack_weight(1, 0, big.ctypes.data, 8, 8, 512, None, ctypes.byref(scale)) > 0
+  assert 0 < scale.value * 1e6 <= 2.0 ** 14
+
+
+def _cases():
+  rng = np.random.default_rng(3)
+  deg = rng.integers(0, 40, 300)
+  deg[7] = 300
+  recv = rng.permutation(np.repeat(np.arange(300), deg)).astype(np.int32)
+  yield "skewed_with_empty", rng.integers(0, 50, len(recv)).astype(np.int32), recv, 300
+  recv = np.repeat(np.arange(200), 3).astype(np.int32)               # uniform degree 3: padded tiles
+  yield "uniform3", rng.integers(0, 9, len(recv)).astype(np.int32), rng.permutation(recv).astype(np.int32), 200
+  recv = np.repeat(np.arange(50), 8).astype(np.int32)                # uniform degree 8: no padding
+  yield "uniform8", rng.integers(0, 9, len(recv)).astype(np.int32), recv, 50
+
+
+@pytest.mark.parametrize("name,senders,receivers,n_recv", list(_cases()), ids=[c[0] for c in _cases()])
+def test_host_pack_edges_equals_numpy_packer(lib, name, senders, receivers, n_recv):
+  want = packing.pack_edges(senders, receivers, n_recv)
+  cap = 64 * (len(receivers) // 21 + 1)
+  perm = np.full(cap, -9, np.int64)
+  snd, rcv = np.full(cap, -9, np.int32), np.full(cap, -9, np.int32)
+  flags = np.full(cap // 64, -9, np.int32)
+  fix, empty = np.full(3 * n_recv, -9, np.int32), np.full(n_recv, -9, np.int32)
+  n_fix, n_empty = ctypes.c_int(-1), ctypes.c_int(-1)
+  n_rows = lib.gc_host_pack_edges(len(receivers), senders.ctypes.data, receivers.ctypes.data, n_recv,
+                                  perm.ctypes.data, snd.ctypes.data, rcv.ctypes.data, flags.ctypes.data,
+                                  fix.ctypes.data, ctypes.byref(n_fix), empty.ctypes.data, ctypes.byref(n_empty))
+  assert n_rows == want.n_rows
+  np.testing.assert_array_equal(perm[:n_rows], want.perm)
+  np.testing.assert_array_equal(snd[:n_rows], want.senders)
+  np.testing.assert_array_equal(rcv[:n_rows], want.receivers)
+  np.testing.assert_array_equal(flags[:n_rows // 64], want.tile_flags)
+  assert n_fix.value == len(want.fix_recv) and n_empty.value == len(want.empty_receivers)
+  f = fix[:3 * n_fix.value].reshape(-1, 3)
+  np.testing.assert_array_equal(f[:, 0], want.fix_recv)
+  np.testing.assert_array_equal(f[:, 1], want.fix_t0)
+  np.testing.assert_array_equal(f[:, 2], want.fix_t1)
+  np.testing.assert_array_equal(empty[:n_empty.value], want.empty_receivers)
+
+
+def test_host_pack_edges_rejects_bad_input(lib):
+  s = np.zeros(4, np.int32)
+  r = np.array([0, 1, 5, 1], np.int32)
+  assert lib.gc_host_pack_edges(4, s.ctypes.data, r.ctypes.data, 3, *([None] * 8)) < 0      # receiver out of range
+  assert lib.gc_host_pack_edges(0, s.ctypes.data, r.ctypes.data, 3, *([None] * 8)) < 0      # empty
+  assert b"gc_host_pack_edges" in lib.gc_last_error()
+
+
+def test_plan_api_argument_checks_without_gpu(lib):
+  handle = ctypes.c_void_p()
+  assert lib.gc_plan_create(None, None, 0, None, ctypes.byref(handle)) == -1
+  assert lib.gc_plan_workspace_bytes(None, 1) == 0
+  assert lib.gc_step_forward(None, None, None, 1, None, 0, None) == -1
+  lib.gc_plan_destroy(None)                         # a no-op, like free(NULL)
+  m = nat.ModelDesc()
+  m.n_grid, m.n_mesh, m.c_in, m.c_out, m.num_steps = 10, 4, 5, 300, 1       # c_out beyond the output tile
+  t = (nat.TensorDesc * 1)(nat.TensorDesc(b"x/w", None, 1, 1))
+  assert lib.gc_plan_create(ctypes.byref(m), t, 1, None, ctypes.byref(handle)) == -1
+  assert b"gc_plan_create" in lib.gc_last_error()
