@@ -234,6 +234,47 @@ class Variable:
     return cls((dim,) + first._dims, _concatenate(arrays, 0))
 
 
+# ----------------------------------------------------------------------------- label indexing
+def _label(x, dtype):
+  """A user label (str / pandas.Timedelta / number ...) in the coordinate's own dtype."""
+  if np.issubdtype(dtype, np.timedelta64):
+    if isinstance(x, np.timedelta64):
+      return x.astype(dtype)
+    import pandas as pd
+    return np.timedelta64(pd.Timedelta(x).value, "ns").astype(dtype)
+  if np.issubdtype(dtype, np.datetime64):
+    return np.datetime64(x).astype(dtype)
+  return x
+
+
+def _positions(coord: "Variable", dim: str, key):
+  """Label-based indexer along `dim` -> positional indexer (xarray `.sel`, exact matches;
+  slices include both end points, as label slices do)."""
+  if coord.ndim != 1:
+    raise ValueError(f"cannot select along {dim!r}: its coordinate is not 1-d")
+  values = coord.values
+  if isinstance(key, slice):
+    if key.step is not None:
+      raise NotImplementedError("label slices with a step")
+    ok = np.ones(len(values), dtype=bool)
+    if key.start is not None:
+      ok &= values >= _label(key.start, values.dtype)
+    if key.stop is not None:
+      ok &= values <= _label(key.stop, values.dtype)
+    idx = np.flatnonzero(ok)
+    if len(idx) and not np.array_equal(idx, np.arange(idx[0], idx[-1] + 1)):
+      raise ValueError(f"label slice along unsorted coordinate {dim!r}")
+    return slice(int(idx[0]), int(idx[-1]) + 1) if len(idx) else slice(0, 0)
+  scalar = np.ndim(key) == 0 and not isinstance(key, (list, tuple))
+  out = []
+  for lab in ([key] if scalar else list(key)):
+    hit = np.flatnonzero(values == _label(lab, values.dtype))
+    if not len(hit):
+      raise KeyError(f"{lab!r} not found in coordinate {dim!r}")
+    out.append(int(hit[0]))
+  return out[0] if scalar else out
+
+
 # ----------------------------------------------------------------------------- coords
 class _Coords(collections.abc.MutableMapping):
   """name -> DataArray; stored as name -> Variable on the owner."""
@@ -364,6 +405,33 @@ class DataArray:
               for k, c in self._coords.items()}
     return self._new(self._variable.isel(indexers), coords)
 
+  def sel(self, indexers=None, **kw):
+    indexers = dict(indexers or {}, **kw)
+    return self.isel({d: _positions(self._coords[d], d, k) for d, k in indexers.items()})
+
+  def __getitem__(self, key):
+    """Positional indexing along the leading dimension(s) (`time[-1]`, `x[:, 0]`)."""
+    key = key if isinstance(key, tuple) else (key,)
+    return self.isel(dict(zip(self.dims, key)))
+
+  def item(self):
+    return self.values.item()
+
+  def squeeze(self, dim=None):
+    dims = [dim] if isinstance(dim, str) else list(dim if dim is not None else
+                                                    [d for d, n in self.sizes.items() if n == 1])
+    for d in dims:
+      if self.sizes[d] != 1:
+        raise ValueError("cannot select a dimension to squeeze out which has length greater than one")
+    return self.isel({d: 0 for d in dims})
+
+  def expand_dims(self, dim, axis=0):
+    """A new leading (axis=0) dimension of size 1; coordinates keep their own dims."""
+    if axis != 0:
+      raise NotImplementedError("expand_dims: only axis=0")
+    var = Variable((dim,) + self.dims, self.data[None])
+    return DataArray(var, coords=dict(self._coords), name=self.name)
+
   def copy(self, deep=True):
     return DataArray(self._variable.copy(deep), coords=dict(self._coords), name=self.name)
 
@@ -401,6 +469,8 @@ class DataArray:
       coords.update(self._coords)
       del sizes
       return DataArray(Variable(dims, op(a.data, bd)), coords=coords, name=self.name)
+    if type(other).__module__.startswith("pandas") and hasattr(other, "to_numpy"):
+      other = other.to_numpy()          # pd.Timedelta / pd.Timestamp -> numpy scalar
     return self._new(Variable(self.dims, op(self.data, other)))
 
   __add__ = lambda s, o: s._binary(o, lambda a, b: a + b)
@@ -516,6 +586,28 @@ class Dataset(collections.abc.Mapping):
     pick = lambda v: v.isel({d: i for d, i in indexers.items() if d in v.dims})
     return Dataset._construct({k: pick(v) for k, v in self._vars.items()},
                               {k: pick(v) for k, v in self._coords.items()})
+
+  def sel(self, indexers=None, **kw):
+    """Label-based selection along dimension coordinates (lists, inclusive slices, scalars)."""
+    indexers = dict(indexers or {}, **kw)
+    for d in indexers:
+      if d not in self._coords:
+        raise KeyError(f"no coordinate for dimension {d!r}")
+    return self.isel({d: _positions(self._coords[d], d, k) for d, k in indexers.items()})
+
+  def squeeze(self, dim=None):
+    dims = [dim] if isinstance(dim, str) else list(dim if dim is not None else
+                                                    [d for d, n in self.sizes.items() if n == 1])
+    for d in dims:
+      if self.sizes[d] != 1:
+        raise ValueError("cannot select a dimension to squeeze out which has length greater than one")
+    return self.isel({d: 0 for d in dims})
+
+  def update(self, other):
+    """In place: adds / replaces variables (name -> Variable | DataArray | (dims, data))."""
+    new = self.assign(other)
+    self._vars, self._coords = new._vars, new._coords
+    return self
 
   def tail(self, indexers=None, **kw):
     indexers = dict(indexers or {}, **kw)

@@ -1,0 +1,247 @@
+"""graphcast_amd.data_utils / solar_radiation (host side, CPU) against
+  * the known-answer values of the reference's own tests (weathernext/utils/data_utils_test.py,
+    solar_radiation_test.py), restated here case by case, and
+  * tests/golden/data_utils_ref.npz = outputs of the reference's own data_utils.py /
+    solar_radiation.py executed unmodified (tests/golden/make_golden_data_utils.py).
+"""
+import datetime
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from graphcast_amd import data_utils
+from graphcast_amd import solar_radiation
+from graphcast_amd import xarray_lite as xa
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data_utils_ref.npz")
+
+
+# ---- reference data_utils_test.py ------------------------------------------------------------------
+def test_year_progress_known_answers():
+  yp = data_utils.get_year_progress(np.array([0, data_utils.AVG_SEC_PER_YEAR, data_utils.AVG_SEC_PER_YEAR * 42]))
+  np.testing.assert_array_equal(yp, np.zeros(3))                 # data_utils_test.py:32-40
+  almost = data_utils.get_year_progress(np.array([data_utils.AVG_SEC_PER_YEAR - 1,
+                                                  (data_utils.AVG_SEC_PER_YEAR - 1) * 42]))
+  assert np.all(almost > 0.999) and np.all(almost < 1.0)         # :42-53
+  assert yp.dtype == np.float32
+
+
+def test_day_progress_known_answers():
+  rng = np.random.default_rng(0)
+  times = rng.integers(0, int(1e10), size=10)
+  lon = np.arange(0, 360.0, 1.0)
+  assert data_utils.get_day_progress(times, lon).shape == (10, 360)                     # :55-62
+  for dt in (datetime.datetime(1988, 11, 7, 2, 45, 34), datetime.datetime(2022, 3, 12, 7, 1, 0)):
+    secs = np.array([(dt - datetime.datetime(1970, 1, 1)).total_seconds()])
+    dp = data_utils.get_day_progress(secs, lon)
+    assert np.all(dp >= 0.0) and np.all(dp < 1.0)                                       # :64-103
+  zero = data_utils.get_day_progress(np.array([0, data_utils.SEC_PER_DAY, data_utils.SEC_PER_DAY * 42]),
+                                     np.array([0.0]))
+  np.testing.assert_array_equal(zero, np.zeros(zero.shape))                             # :105-115
+  np.testing.assert_array_almost_equal(data_utils.get_day_progress(np.array([123]), np.array([0.0])),
+                                       np.array([[0.00142361]]), decimal=6)             # :117-124
+
+
+def test_featurize_progress_known_answers():
+  day_progress = np.array([0.0, 0.45, 0.213])
+  f = data_utils.featurize_progress(name="day_progress", dims=("time",), progress=day_progress)
+  for v in f.values():
+    assert tuple(v.dims) == ("time",)
+  np.testing.assert_array_equal(day_progress, f["day_progress"].values)
+  np.testing.assert_array_almost_equal([0.0, 0.30901699, 0.97309851], f["day_progress_sin"].values, decimal=6)
+  np.testing.assert_array_almost_equal([1.0, -0.95105652, 0.23038943], f["day_progress_cos"].values, decimal=6)
+  with pytest.raises(ValueError):                                                       # :160-167
+    data_utils.featurize_progress(name="year_progress", dims=("time", "longitude"), progress=day_progress)
+
+
+def _xlon_dataset(extra=None):
+  dims = ["x", "lon", "datetime"]
+  dv = {"var1": (dims, 8 * np.random.default_rng(0).standard_normal((2, 2, 3)))}
+  dv.update(extra or {})
+  return xa.Dataset(data_vars=dv, coords={
+      "lon": np.array([0.0, 0.5]),
+      "datetime": np.array([datetime.datetime(2021, 1, 1), datetime.datetime(2023, 1, 1),
+                            datetime.datetime(2023, 1, 3)], dtype="datetime64[ns]")})
+
+
+def test_add_derived_vars_adds_keeps_and_validates():
+  # the reference's fixture names its time dimension "datetime"; featurize uses dims ("time", lon dims)
+  data = xa.Dataset(data_vars={"var1": (["time", "lon"], np.ones((3, 2)))},
+                    coords={"lon": np.array([0.0, 0.5]),
+                            "datetime": ("time", np.array(["2021-01-01", "2023-01-01", "2023-01-03"], dtype="datetime64[ns]"))})
+  data_utils.add_derived_vars(data)
+  names = set(data.variables)
+  assert {"var1", data_utils.YEAR_PROGRESS, data_utils.DAY_PROGRESS, "year_progress_sin", "day_progress_cos"} <= names
+  dims = ["time", "lon"]
+  data = xa.Dataset(data_vars={"var1": (dims, np.ones((3, 2))),
+                               data_utils.YEAR_PROGRESS: (dims, np.full((3, 2), 0.111)),
+                               data_utils.DAY_PROGRESS: (dims, np.full((3, 2), 0.222))},
+                    coords={"lon": np.array([0.0, 0.5]),
+                            "datetime": ("time", np.array(["2021-01-01", "2023-01-01", "2023-01-03"], dtype="datetime64[ns]"))})
+  data_utils.add_derived_vars(data)                                                     # :196-221
+  np.testing.assert_allclose(data[data_utils.YEAR_PROGRESS].values, 0.111)
+  np.testing.assert_allclose(data[data_utils.DAY_PROGRESS].values, 0.222)
+  for coord_name in ("lon", "datetime"):                                                # :223-239
+    bad = xa.Dataset(data_vars={"var1": (["x", coord_name], np.ones((2, 2)))}, coords={coord_name: np.array([0.0, 0.5])})
+    with pytest.raises(ValueError):
+      data_utils.add_derived_vars(bad)
+
+
+def _tisr_dataset(batch=None, with_tisr=False):
+  lead = (["batch"] if batch else []) + ["time", "lat", "lon"]
+  shape = ((batch,) if batch else ()) + (2, 2, 2)
+  dv = {"var1": (lead, np.full(shape, 8.0))}
+  if with_tisr:
+    dv[data_utils.TISR] = (lead, np.full(shape, 1200.0))
+  dt = np.array([10, 20], dtype="datetime64[D]")
+  if batch:
+    dt = np.stack([dt + np.timedelta64(90 * b, "D") for b in range(batch)])
+  return xa.Dataset(data_vars=dv, coords={
+      "lat": np.array([2.0, 1.0]), "lon": np.array([0.0, 0.5]),
+      "time": np.array([100, 200], dtype="timedelta64[s]"),
+      "datetime": xa.Variable((("batch", "time") if batch else ("time",)), dt)})
+
+
+def test_add_tisr_var_cases():
+  data = _tisr_dataset()
+  data_utils.add_tisr_var(data)                                                         # :241-259
+  assert data_utils.TISR in set(data.variables) and data[data_utils.TISR].shape == (2, 2, 2)
+  data = _tisr_dataset(with_tisr=True)
+  data_utils.add_tisr_var(data)                                                         # :261-281
+  np.testing.assert_allclose(data[data_utils.TISR].values, 1200.0)
+  data = _tisr_dataset(batch=1)
+  data_utils.add_tisr_var(data)                                                         # :283-305
+  assert data[data_utils.TISR].dims == ("batch", "time", "lat", "lon")
+  with pytest.raises(ValueError, match=r"cannot select a dimension"):                   # :307-330
+    data_utils.add_tisr_var(_tisr_dataset(batch=2))
+
+
+# ---- reference solar_radiation_test.py -------------------------------------------------------------
+def test_solar_radiation_argument_checks_and_shapes():
+  data = xa.DataArray(np.zeros((2, 2)), coords=[("lon", np.array([0.1, 0.2])), ("x", np.array([0.0, 0.5]))])
+  with pytest.raises(ValueError, match=r".* dimensions are missing in `data_array_like`."):
+    solar_radiation.get_toa_incident_solar_radiation_for_xarray(data, integration_period="1h", num_integration_bins=360)
+  data = xa.Dataset(data_vars={"var1": (["x", "lat", "lon"], np.zeros((2, 3, 2)))},
+                    coords={"lat": np.array([0.0, 0.1, 0.2]), "lon": np.array([0.0, 0.5])})
+  with pytest.raises(ValueError, match=r".* coordinates are missing in `data_array_like`."):
+    solar_radiation.get_toa_incident_solar_radiation_for_xarray(data, integration_period="1h", num_integration_bins=360)
+  data = xa.Dataset(data_vars={"var1": (["time", "lat", "lon"], np.zeros((2, 4, 2)))},
+                    coords={"lat": np.array([0.0, 0.1, 0.2, 0.3]), "lon": np.array([0.0, 0.5]),
+                            "time": np.array([100, 200], dtype="timedelta64[s]"),
+                            "datetime": xa.Variable("time", np.array([10, 20], dtype="datetime64[D]"))})
+  out = solar_radiation.get_toa_incident_solar_radiation_for_xarray(data, integration_period="1h", num_integration_bins=2)
+  assert out.dims == ("time", "lat", "lon") and out.shape == (2, 4, 2)                  # :76-97
+  assert set(out.coords) >= {"lat", "lon", "time", "datetime"}
+  single = xa.Dataset(data_vars={"var1": (["lat", "lon"], np.zeros((4, 2)))},
+                      coords={"lat": np.array([0.0, 0.1, 0.2, 0.3]), "lon": np.array([0.0, 0.5]),
+                              "datetime": np.datetime64(10, "D")})
+  out = solar_radiation.get_toa_incident_solar_radiation_for_xarray(single, integration_period="1h", num_integration_bins=2)
+  assert out.dims == ("lat", "lon") and out.shape == (4, 2)                             # :99-114
+
+
+def test_get_tsi_known_answers():
+  t = [np.datetime64("2020-07-02T00:00:00")]
+  np.testing.assert_allclose(solar_radiation.get_tsi(t, solar_radiation.reference_tsi_data()), [1361.0])
+  np.testing.assert_allclose(solar_radiation.get_tsi(t, solar_radiation.era5_tsi_data()), [1360.9440], rtol=1e-7)
+  tsi_data = xa.DataArray(np.array([1000.0, 1300.0, 1200.0]), dims=["time"], coords={"time": np.array([2020.5, 2021.5, 2022.5])})
+  for stamp, want in (("2020-01-01T00:00:00", 1000.0), ("2020-07-02T00:00:00", 1000.0), ("2021-01-01T00:00:00", 1150.0),
+                      ("2021-07-02T12:00:00", 1300.0), ("2022-01-01T00:00:00", 1250.0), ("2022-07-02T12:00:00", 1200.0),
+                      ("2023-01-01T00:00:00", 1200.0)):                                 # :188-240
+    np.testing.assert_allclose(solar_radiation.get_tsi([np.datetime64(stamp)], tsi_data), [want])
+
+
+# ---- outputs of the reference's own code ------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gold():
+  return np.load(GOLD)
+
+
+def test_solar_radiation_matches_reference_execution(gold):
+  stamps = gold["sr_stamps"].astype("datetime64[s]")
+  got = solar_radiation.get_toa_incident_solar_radiation(stamps, gold["sr_lat"], gold["sr_lon"], use_jit=True)
+  want = gold["sr_tisr"]
+  assert got.dtype == np.float32 and got.shape == want.shape
+  # same float32 arithmetic, operation for operation: identical up to the last bits of the sums
+  np.testing.assert_allclose(got, want, rtol=2e-6, atol=0.5)          # values up to ~5e6 J/m^2
+  assert np.abs(got - want).max() <= 1e-6 * want.max()
+  got6 = solar_radiation.get_toa_incident_solar_radiation(stamps[:2], gold["sr_lat"], gold["sr_lon"],
+                                                          integration_period="6h", num_integration_bins=12)
+  np.testing.assert_allclose(got6, gold["sr_tisr_6h_12bins"], rtol=2e-6, atol=2.0)
+  np.testing.assert_allclose(solar_radiation.get_tsi(stamps, solar_radiation.era5_tsi_data()), gold["sr_tsi"], rtol=0, atol=0)
+  # physics sanity: night side is exactly zero, the sub-solar belt near TSI * 3600 s
+  assert (want >= 0).all() and want.min() == 0.0 and 4.5e6 < want.max() < 5.1e6
+  # what the float32 day count costs: the float64 integral is visibly different (~1e-4 of the peak
+  # here), i.e. 100x the agreement required above -- the float32 path is the one that is pinned
+  exact = solar_radiation.get_toa_incident_solar_radiation(stamps, gold["sr_lat"], gold["sr_lon"], dtype=np.float64)
+  assert 1e-5 * want.max() < np.abs(exact - want).max() < 1e-2 * want.max()
+
+
+def _raw_dataset(gold):
+  return xa.Dataset(
+      data_vars={"2m_temperature": (("batch", "time", "lat", "lon"), gold["raw/2m_temperature"]),
+                 "temperature": (("batch", "time", "level", "lat", "lon"), gold["raw/temperature"]),
+                 "geopotential_at_surface": (("lat", "lon"), gold["raw/geopotential_at_surface"])},
+      coords={"lat": gold["raw_lat"], "lon": gold["raw_lon"], "level": gold["raw_level"],
+              "time": gold["raw_time"].astype("timedelta64[ns]"),
+              "datetime": (("batch", "time"), gold["raw_datetime"].astype("datetime64[ns]")[None])})
+
+
+KW = dict(input_variables=("2m_temperature", "temperature", "geopotential_at_surface", "toa_incident_solar_radiation",
+                           "year_progress_sin", "day_progress_cos"),
+          target_variables=("2m_temperature", "temperature"),
+          forcing_variables=("toa_incident_solar_radiation", "year_progress_sin", "year_progress_cos",
+                             "day_progress_sin", "day_progress_cos"),
+          pressure_levels=(50, 850), input_duration="12h", target_lead_times=slice("6h", "18h"))
+
+
+def test_extract_inputs_targets_forcings_matches_reference_execution(gold):
+  inputs, targets, forcings = data_utils.extract_inputs_targets_forcings(_raw_dataset(gold), **KW)
+  for tag, d in (("in", inputs), ("tg", targets), ("fc", forcings)):
+    np.testing.assert_array_equal(np.asarray(d.coords["time"].data).astype("timedelta64[ns]").astype(np.int64),
+                                  gold[f"du_{tag}_time"])
+    names = sorted(k.split("/", 1)[1] for k in gold.files if k.startswith(f"du_{tag}/"))
+    assert sorted(d.data_vars) == names
+    for name in names:
+      assert "|".join(d[name].dims) == str(gold[f"du_{tag}_dims/{name}"])
+      got, want = np.asarray(d[name].data), gold[f"du_{tag}/{name}"]
+      assert got.shape == want.shape and got.dtype == want.dtype, name
+      if name == data_utils.TISR:
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=0.5)
+      else:
+        np.testing.assert_array_equal(got, want)
+  np.testing.assert_array_equal(np.asarray(inputs.coords["level"].data), [50, 850])
+  assert list(np.asarray(inputs.coords["time"].data).astype("timedelta64[h]").astype(int)) == [-6, 0]
+  assert "datetime" not in inputs.coords
+  # a list of lead times, given out of order
+  _, targets2, _ = data_utils.extract_inputs_targets_forcings(_raw_dataset(gold), **dict(KW, target_lead_times=("18h", "6h")))
+  np.testing.assert_array_equal(np.asarray(targets2.coords["time"].data).astype("timedelta64[ns]").astype(np.int64), gold["du_tg2_time"])
+  np.testing.assert_array_equal(np.asarray(targets2["2m_temperature"].data), gold["du_tg2/2m_temperature"])
+  with pytest.raises(ValueError, match="should not overlap"):
+    data_utils.extract_inputs_targets_forcings(_raw_dataset(gold), **dict(KW, forcing_variables=("2m_temperature",)))
+
+
+def test_progress_features_match_reference_execution(gold):
+  np.testing.assert_array_equal(data_utils.get_year_progress(gold["prog_secs"]), gold["prog_year"])
+  np.testing.assert_array_equal(data_utils.get_day_progress(gold["prog_secs"], gold["raw_lon"]), gold["prog_day"])
+
+
+def test_extracted_sample_feeds_the_task_config_shapes():
+  """The split produces exactly the (batch, time, lat, lon[, level]) Datasets GraphCast.__call__
+  stacks (graphcast.py:680-699): 2 input frames, 1 target frame, forcings at the target times."""
+  rng = np.random.default_rng(1)
+  nt = 3
+  time = (np.arange(nt) * np.timedelta64(6, "h")).astype("timedelta64[ns]")
+  ds = xa.Dataset(
+      data_vars={"2m_temperature": (("batch", "time", "lat", "lon"), rng.standard_normal((1, nt, 4, 6)).astype(np.float32)),
+                 "temperature": (("batch", "time", "level", "lat", "lon"), rng.standard_normal((1, nt, 3, 4, 6)).astype(np.float32))},
+      coords={"lat": np.linspace(-90, 90, 4), "lon": np.linspace(0, 360, 6, endpoint=False), "level": np.array([100, 500, 1000]),
+              "time": time, "datetime": (("batch", "time"), (np.datetime64("2022-01-01T00", "ns") + time)[None])})
+  inputs, targets, forcings = data_utils.extract_inputs_targets_forcings(
+      ds, input_variables=("2m_temperature", "temperature", "toa_incident_solar_radiation"),
+      target_variables=("2m_temperature", "temperature"), forcing_variables=("toa_incident_solar_radiation",),
+      pressure_levels=(100, 500, 1000), input_duration="12h", target_lead_times="6h")
+  assert inputs.sizes["time"] == 2 and targets.sizes["time"] == 1 and forcings.sizes["time"] == 1
+  assert inputs["temperature"].dims == ("batch", "time", "level", "lat", "lon")
+  assert pd.Timedelta(np.asarray(targets.coords["time"].data)[0]) == pd.Timedelta("6h")
