@@ -29,6 +29,11 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA peak (same guide; 2:1-sparse figures excluded)
+# What the matrix cores SUSTAIN on this chip with non-zero operands (power-limited clock), measured
+# with scripts/ubench/colown_stream.hip on all 256 CUs, 120-150 ms kernels, random f16 operands:
+# bare v_mfma_f32_32x32x16_f16 stream 69 % of peak, with the weight stream from L2 + row fragments
+# from LDS 55 % (profiles/r01_co21_sustained_mfma_random_vs_zero.txt; zero operands: 98 % / 88 %).
+SUSTAINED_F16_MFMA_TFLOPS = {"mfma_only": 0.69 * 2500.0, "mfma_with_operand_streams": 0.55 * 2500.0}
 LATENT = 512
 
 CONFIGS = {
@@ -269,12 +274,16 @@ def main():
             "batch_per_gpu": 1},
         "roofline": {
             "bound": "mfma",
-            "kernel": f"{ {'f16x3': 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16': 'rowmlpb_kernel'}[precision] }"
+            "kernel": f"{ {'f16x3': 'rowmlpc_kernel' if getattr(engine, 'colown', False) else 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16': 'rowmlpb_kernel'}[precision] }"
                       f"<MLP_LN> stage {dominant}",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,
             "mfma_flops_per_algorithmic_flop": issue,
             "mfma_issue_frac": issue * achieved / peak,
+            # the same MFMA work against what the chip sustains under power with real operands
+            "sustained_peak_measured": (None if precision == "f32" else SUSTAINED_F16_MFMA_TFLOPS),
+            "mfma_issue_frac_of_sustained": (None if precision == "f32" else
+                                             issue * achieved / SUSTAINED_F16_MFMA_TFLOPS["mfma_with_operand_streams"]),
             "launches_per_step": dom["launches"],
             "avg_launch_ms": dom["ms"] / dom["launches"],
             "traffic": (measured_traffic(f"{precision}:{dominant}") or {}).get("bytes_per_launch"),
