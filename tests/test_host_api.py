@@ -448,3 +448,35 @@ def test_checkpoint_written_by_the_reference_loads(golden_dir):
   assert ck.description == "golden"
   w = ck.params["grid2mesh_gnn/~_networks_builder/encoder_edges_grid2mesh_mlp/~/linear_0"]["w"]
   np.testing.assert_array_equal(w, np.random.default_rng(0).standard_normal((4, 8)).astype(np.float32))
+
+
+def test_xarray_lite_label_selection_squeeze_expand_update():
+  """The xarray subset data_utils needs (reference data_utils.py:215-362): label-based `sel`
+  (lists, inclusive slices, scalars; timedelta labels given as strings / pandas / numpy),
+  `squeeze`, `expand_dims`, in-place `update`."""
+  import pandas as pd
+  from graphcast_amd import xarray_lite as xl
+  time = (np.arange(5) * np.timedelta64(6, "h")).astype("timedelta64[ns]")
+  ds = xl.Dataset({"a": (("batch", "time", "level"), np.arange(15, dtype=np.float32).reshape(1, 5, 3))},
+                  coords={"time": time, "level": np.array([50, 500, 850])})
+  np.testing.assert_array_equal(ds.sel(level=[850, 50])["a"].values[0, 0], [2.0, 0.0])      # order of the request
+  assert ds.sel(level=500)["a"].dims == ("batch", "time")                                   # scalar drops the dim
+  sl = ds.sel(time=slice(pd.Timedelta("6h"), "18h"))
+  assert sl.sizes["time"] == 3 and sl.coords["time"].values[0] == np.timedelta64(6, "h")    # both ends included
+  assert ds.sel(time=slice(None, np.timedelta64(6, "h"))).sizes["time"] == 2
+  assert ds.sel(time=slice("25h", None)).sizes["time"] == 0
+  assert ds.sel(time=["12h"]).sizes["time"] == 1
+  with pytest.raises(KeyError):
+    ds.sel(level=[123])
+  with pytest.raises(KeyError):
+    ds.sel(nope=[1])
+  assert ds.squeeze("batch")["a"].dims == ("time", "level")
+  with pytest.raises(ValueError, match="cannot select a dimension to squeeze"):
+    ds.squeeze("time")
+  da = ds["a"].squeeze("batch").expand_dims("batch", axis=0)
+  assert da.dims == ("batch", "time", "level") and da.shape == (1, 5, 3)
+  assert ds["a"][0, -1].shape == (3,) and float(ds["a"][0, -1, 2].item()) == 14.0
+  same = ds.update({"b": xl.Variable(("time",), np.ones(5))})
+  assert same is ds and "b" in ds.data_vars and ds["b"].dims == ("time",)
+  shifted = ds.coords["time"] + pd.Timedelta("6h") - ds.coords["time"][-1]
+  assert shifted.values[-1] == np.timedelta64(6, "h")
