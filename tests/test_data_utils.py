@@ -245,3 +245,41 @@ def test_extracted_sample_feeds_the_task_config_shapes():
   assert inputs.sizes["time"] == 2 and targets.sizes["time"] == 1 and forcings.sizes["time"] == 1
   assert inputs["temperature"].dims == ("batch", "time", "level", "lat", "lon")
   assert pd.Timedelta(np.asarray(targets.coords["time"].data)[0]) == pd.Timedelta("6h")
+
+
+def test_notebook_call_pattern_feeds_graphcast_channel_counts():
+  """graphcast_demo.ipynb's call -- extract_inputs_targets_forcings(batch, target_lead_times=...,
+  **dataclasses.asdict(task_config)) -- on a raw ERA5-like sample yields Datasets whose stacked
+  channel counts are the ones GraphCast's first and last layers expect (183 in /
+  83 out at 13 levels)."""
+  import dataclasses
+  from graphcast_amd import graphcast as gc
+  from graphcast_amd import model_utils
+  from graphcast_amd import variables as V
+  tc = gc.TASK_13
+  rng = np.random.default_rng(0)
+  nt, nlat, nlon = 3, 5, 8
+  levels = np.array(V.PRESSURE_LEVELS_ERA5_37)                  # more levels than the task uses
+  time = (np.arange(nt) * np.timedelta64(6, "h")).astype("timedelta64[ns]")
+  dv = {}
+  for name in sorted(set(tc.input_variables) | set(tc.target_variables)):
+    if name in data_utils._DERIVED_VARS or name == data_utils.TISR:
+      continue                                                  # derived by data_utils itself
+    if name in V.STATIC_VARS:
+      dv[name] = (("lat", "lon"), rng.standard_normal((nlat, nlon)).astype(np.float32))
+    elif name in V.ALL_ATMOSPHERIC_VARS:
+      dv[name] = (("batch", "time", "level", "lat", "lon"),
+                  rng.standard_normal((1, nt, len(levels), nlat, nlon)).astype(np.float32))
+    else:
+      dv[name] = (("batch", "time", "lat", "lon"), rng.standard_normal((1, nt, nlat, nlon)).astype(np.float32))
+  raw = xa.Dataset(dv, coords={"lat": np.linspace(-90, 90, nlat), "lon": np.linspace(0, 360, nlon, endpoint=False),
+                               "level": levels, "time": time,
+                               "datetime": (("batch", "time"), (np.datetime64("2022-01-01T00", "ns") + time)[None])})
+  inputs, targets, forcings = data_utils.extract_inputs_targets_forcings(
+      raw, target_lead_times=slice("6h", "6h"), **dataclasses.asdict(tc))
+  assert inputs.sizes["time"] == 2 and targets.sizes["time"] == 1 and inputs.sizes["level"] == 13
+  assert set(forcings.data_vars) == set(tc.forcing_variables)
+  n_in = (model_utils.dataset_to_stacked(inputs).sizes["channels"]
+          + model_utils.dataset_to_stacked(forcings).sizes["channels"])
+  assert n_in == 183                                            # + 3 structural = 186 (SURVEY 8)
+  assert model_utils.dataset_to_stacked(targets).sizes["channels"] == gc.num_output_channels(tc) == 83
