@@ -44,6 +44,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #ifndef GC_PIPE
 #define GC_PIPE 2        // split-f16 path: where the per-chunk barrier sits (see mma16_group)
 #endif
+#ifndef GC_ASM_FLUSH
+#define GC_ASM_FLUSH 1   // segment-sum run flush as an inline-asm store (see finish_rows; -1.1 % per launch)
+#endif
 #ifndef GC_TRACE
 #define GC_TRACE 0       // profiling ONLY: rowmlp16 writes phase timestamps of wave 0 to d.partial
 #endif                   // (launches without segment-sum; scripts/kernel_probe.py)
@@ -592,7 +595,15 @@ __device__ __forceinline__ void finish_rows(f4 (&o2)[kNB], const gc_rowmlp_desc&
         } else {
           dst = d.agg + (size_t)cur * kD;
         }
+#if GC_ASM_FLUSH
+        // as inline asm: hipcc does not see the store, so it does not drain vmcnt at the join of
+        // this conditional (one write-acknowledge latency per run otherwise); s_endpgm waits for it
+        const unsigned long long bits = (unsigned long long)__float_as_uint(sx) |
+                                        ((unsigned long long)__float_as_uint(sy) << 32);
+        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst + c2), "v"(bits) : "memory");
+#else
         *reinterpret_cast<float2*>(dst + c2) = make_float2(sx, sy);
+#endif
       }
     };
 #pragma unroll 1
