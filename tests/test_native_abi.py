@@ -56,3 +56,26 @@ def test_argument_validation_needs_no_gpu(built):
   assert lib.gc_rowmlp(ctypes.byref(d), None) == -1
   assert b"multiples of 32" in lib.gc_last_error()
   assert lib.gc_prep_grid_input(10, 1, 0, 471, None, 3, None, 474, None, None) == -1
+
+
+def test_header_is_plain_c_and_the_c_host_example_links():
+  """include/gcast.h must be consumable from C (the drop-in boundary is a C-ABI): the example host
+  compiles as strict C99 and links against the built library (it needs a GPU to RUN; on the MI355X
+  box it printed a finite checksum, see examples/plan_host.c)."""
+  import shutil
+  import subprocess
+  import tempfile
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  gcc = shutil.which("gcc")
+  if gcc is None:
+    pytest.skip("no gcc")
+  src = os.path.join(root, "examples", "plan_host.c")
+  subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                  "-fsyntax-only", src], check=True)
+  rocm_lib = "/opt/rocm/lib"
+  if not os.path.exists(os.path.join(rocm_lib, "libamdhip64.so")):
+    pytest.skip("no HIP runtime to link against")
+  with tempfile.TemporaryDirectory() as tmp:
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), src,
+                    "-L", os.path.join(root, "graphcast_amd", "csrc"), "-lgcast_hip", "-L", rocm_lib, "-lamdhip64",
+                    "-lm", "-o", os.path.join(tmp, "plan_host")], check=True)
