@@ -132,8 +132,7 @@ def main():
     return d, 48, n_g
 
   shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, linear_grid=linear_grid, node_grid=node_grid)
-  builds = [("pipe2", ["-DGC_PIPE=2"]), ("pipe2_asmflush", ["-DGC_PIPE=2", "-DGC_ASM_FLUSH=1"]),
-            ("pipe2_again", ["-DGC_PIPE=2"]), ("pipe2_asmflush_again", ["-DGC_PIPE=2", "-DGC_ASM_FLUSH=1"]),
+  builds = [("pipe2", ["-DGC_PIPE=2"]), ("pipe2_c_flush", ["-DGC_PIPE=2", "-DGC_ASM_FLUSH=0"]),
             ("pipe2_dma_builtin", ["-DGC_PIPE=2", "-DGC_DMA_ASM=0"]),
             ("pipe2_noride", ["-DGC_PIPE=2", "-DGC_RIDE=0"]),
             ("pipe2_nodmawait", ["-DGC_PIPE=2", "-DGC_EXP=8"]),
