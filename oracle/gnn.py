@@ -96,10 +96,17 @@ def segment_sum(data, segment_ids, num_segments):
 
 
 class Net:
-  """MLP(+LayerNorm) addressed by its reference module name."""
+  """MLP(+LayerNorm) addressed by its reference module name.
 
-  def __init__(self, params, gnn_name, dtype):
+  ``norm_conditioning`` [batch, C_cond] switches every LayerNorm to the reference's conditional
+  form (deep_typed_graph_net.py:210-246 + dense.py:360-393, the GenCast encoder / decoder):
+  LayerNorm WITHOUT learned scale / offset, then ``x * (1 + s) + o`` with
+  ``[s | o] = norm_conditioning @ w + b`` of the module ``<name>_norm_conditioning/linear``,
+  broadcast over the node / edge axis (``global_norm_conditioning[None]``)."""
+
+  def __init__(self, params, gnn_name, dtype, norm_conditioning=None):
     self._p, self._g, self._dt = params, gnn_name, dtype
+    self._cond = None if norm_conditioning is None else np.asarray(norm_conditioning, dtype=dtype)
 
   def _get(self, module, leaf):
     key = f"{self._g}/~_networks_builder/{module}"
@@ -116,7 +123,13 @@ class Net:
                      self._get(f"{name}_mlp/~/linear_{k}", "b")))
       k += 1
     y = mlp(x, layers)
-    if use_layer_norm:
+    if use_layer_norm and self._cond is not None:
+      y = layer_norm(y, 1.0, 0.0)
+      so = self._cond @ self._get(f"{name}_norm_conditioning/linear", "w") \
+          + self._get(f"{name}_norm_conditioning/linear", "b")                  # [batch, 2 C]
+      c = y.shape[-1]
+      y = y * (so[..., :c] + 1.0)[None] + so[..., c:][None]
+    elif use_layer_norm:
       y = layer_norm(y, self._get(f"{name}_layer_norm", "scale"),
                      self._get(f"{name}_layer_norm", "offset"))
     return y
@@ -137,7 +150,7 @@ def _edge_update(net, name, edge, nodes, chunk):
 def deep_typed_graph_net(params, gnn_name, graph, *, num_steps, embed_nodes,
                          embed_edges, node_output=(), dtype=np.float64,
                          chunk=1 << 16, live_nodes=None, live_edges=None,
-                         f32_aggregation=False):
+                         f32_aggregation=False, norm_conditioning=None):
   """Returns {"nodes": {...}, "edges": {...}} of output features.
 
   ``live_nodes`` / ``live_edges`` optionally restrict which outputs are computed
@@ -148,8 +161,11 @@ def deep_typed_graph_net(params, gnn_name, graph, *, num_steps, embed_nodes,
   ``f32_aggregation`` restates ``deep_typed_graph_net.py:273-281``: the edge messages are
   cast to float32 around the segment-sum and the result cast back (an up-cast for the
   reference's bf16 activations, a no-op in fp32, a DOWN-cast when the oracle runs in float64).
+
+  ``norm_conditioning`` [batch, C_cond]: the reference's ``use_norm_conditioning=True`` /
+  ``global_norm_conditioning`` (see ``Net``).
   """
-  net = Net(params, gnn_name, dtype)
+  net = Net(params, gnn_name, dtype, norm_conditioning=norm_conditioning)
   nodes = {k: np.asarray(v, dtype=dtype) for k, v in graph["nodes"].items()}
   edges = {k: dict(v, features=np.asarray(v["features"], dtype=dtype))
            for k, v in graph["edges"].items()}
