@@ -578,14 +578,18 @@ class Dataset(collections.abc.Mapping):
   def compute(self):
     return self
 
-  def isel(self, indexers=None, **kw):
+  def isel(self, indexers=None, drop=False, **kw):
+    """Positional selection; `drop=True` removes the coordinates an integer index turns into
+    scalars (xarray's meaning), instead of keeping them as 0-d coordinates."""
     indexers = dict(indexers or {}, **kw)
     bad = set(indexers) - set(self.sizes)
     if bad:
       raise ValueError(f"Dimensions {bad} do not exist. Expected one or more of {tuple(self.sizes)}")
     pick = lambda v: v.isel({d: i for d, i in indexers.items() if d in v.dims})
-    return Dataset._construct({k: pick(v) for k, v in self._vars.items()},
-                              {k: pick(v) for k, v in self._coords.items()})
+    scalar_dims = {d for d, i in indexers.items() if isinstance(i, (int, np.integer))}
+    coords = {k: pick(v) for k, v in self._coords.items()
+              if not (drop and k in scalar_dims and v.dims == (k,))}
+    return Dataset._construct({k: pick(v) for k, v in self._vars.items()}, coords)
 
   def sel(self, indexers=None, **kw):
     """Label-based selection along dimension coordinates (lists, inclusive slices, scalars)."""

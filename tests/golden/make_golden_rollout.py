@@ -116,6 +116,28 @@ def main():
   out["time"] = np.asarray(preds.coords["time"].values).astype("timedelta64[ns]").astype(np.int64)
   out["first_stacked_input"] = state["first_stacked_input"]
   out["config"] = np.array([STEPS, SEED, STATS_SEED, W_SEED])
+
+  # ---- ensemble rollouts: chunked_prediction_generator_multiple_runs (rollout.py:158-307), the
+  # un-pmapped branch, with a `sample` axis on the inputs (3 members = 3 perturbed initial states)
+  n_members = 3
+  rng = np.random.default_rng(77)
+  members = []
+  for m in range(n_members):
+    pert = {k: inputs[k] * np.float32(1.0 + 0.05 * m) for k in inputs.keys()}
+    members.append(xarray_lite.Dataset(pert, coords=dict(inputs.coords)))
+  ens_inputs = xarray_lite.concat(members, dim="sample")
+  del rng
+  chunks = list(ref_rollout.chunked_prediction_generator_multiple_runs(
+      lambda rng, inputs, targets_template, forcings: wrapped(inputs, targets_template, forcings),
+      rngs=np.arange(2 * n_members, dtype=np.uint32).reshape(n_members, 2), inputs=ens_inputs,
+      targets_template=template, forcings=forcings, num_samples=None, num_steps_per_chunk=1))
+  out["ens_n_chunks"] = np.array(len(chunks))
+  out["ens_sample_of_chunk"] = np.array([int(np.asarray(c.coords["sample"].values)) for c in chunks])
+  out["ens_time_of_chunk"] = np.array([np.asarray(c.coords["time"].values).astype("timedelta64[ns]").astype(np.int64)[0]
+                                       for c in chunks])
+  key = "2m_temperature"
+  out["ens_2m_temperature"] = np.stack([np.asarray(c[key].values) for c in chunks])
+  out["ens_dims"] = np.array("|".join(chunks[0][key].dims))
   path = os.path.join(HERE, "rollout_ref.npz")
   np.savez_compressed(path, **out)
   print("wrote", path, {k: v.shape for k, v in out.items() if k.startswith("pred:")})

@@ -12,6 +12,10 @@ class _Logging:
   def log_first_n(level, msg, n, *args):
     pass
 
+  @staticmethod
+  def flush():
+    pass
+
   INFO, WARNING, ERROR = 0, 1, 2
 
 

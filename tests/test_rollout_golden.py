@@ -77,3 +77,40 @@ def test_autoregressive_predictor_matches_reference_execution(golden_dir):
   for k in sorted(k[5:] for k in z.files if k.startswith("pred:")):
     assert "|".join(preds[k].dims) == str(z[f"dims:{k}"]), k       # time-leading, like hk.scan's stacking
     np.testing.assert_allclose(preds[k].values, z[f"pred:{k}"], rtol=1e-6, atol=1e-6, err_msg=k)
+
+
+def test_ensemble_generator_matches_reference_execution(ref):
+  """chunked_prediction_generator_multiple_runs (reference rollout.py:158-307, un-pmapped branch)
+  executed by the reference on an inputs Dataset with a `sample` axis: chunk order (all lead times
+  of a member before the next member), the scalar `sample` coordinate of every chunk, and the
+  values -- and the same members when the work is sharded over two ranks."""
+  steps, seed, stats_seed, w_seed = (int(v) for v in ref["config"])
+  inputs, template, forcings = synthetic.make_example(TASK, LAT, LON, num_target_steps=steps, seed=seed)
+  mean, std, dstd = synthetic.make_stats(TASK, seed=stats_seed)
+  wrapped = normalization.InputsAndResiduals(Toy(w_seed), std, mean, dstd)
+  n_members = 3
+  members = [xarray.Dataset({k: inputs[k] * np.float32(1.0 + 0.05 * m) for k in inputs.keys()},
+                            coords=dict(inputs.coords)) for m in range(n_members)]
+  ens_inputs = xarray.concat(members, dim="sample")
+  fn = lambda rng, **kw: wrapped(**kw)
+  rngs = np.arange(2 * n_members, dtype=np.uint32).reshape(n_members, 2)
+  chunks = list(rollout.chunked_prediction_generator_multiple_runs(
+      fn, rngs, ens_inputs, template, forcings, num_samples=None, num_steps_per_chunk=1))
+  assert len(chunks) == int(ref["ens_n_chunks"]) == n_members * steps
+  np.testing.assert_array_equal([int(np.asarray(c.coords["sample"].values)) for c in chunks], ref["ens_sample_of_chunk"])
+  np.testing.assert_array_equal(
+      [np.asarray(c.coords["time"].values).astype("timedelta64[ns]").astype(np.int64)[0] for c in chunks],
+      ref["ens_time_of_chunk"])
+  assert "|".join(chunks[0]["2m_temperature"].dims) == str(ref["ens_dims"])
+  got = np.stack([np.asarray(c["2m_temperature"].values) for c in chunks])
+  np.testing.assert_allclose(got, ref["ens_2m_temperature"], rtol=0, atol=2e-6)
+  # one process per GPU: rank r of 2 rolls out members r, r + 2, ... -- the union is the same set
+  by_rank = [list(rollout.chunked_prediction_generator_multiple_runs(
+      fn, rngs, ens_inputs, template, forcings, num_samples=None, num_steps_per_chunk=1, rank=r, world_size=2))
+      for r in (0, 1)]
+  assert [int(np.asarray(c.coords["sample"].values)) for c in by_rank[0]] == [0] * steps + [2] * steps
+  assert [int(np.asarray(c.coords["sample"].values)) for c in by_rank[1]] == [1] * steps
+  for c in by_rank[1]:
+    i = steps + [int(np.asarray(x.coords["time"].values).astype("timedelta64[ns]").astype(np.int64)[0]) for x in by_rank[1]].index(
+        int(np.asarray(c.coords["time"].values).astype("timedelta64[ns]").astype(np.int64)[0]))
+    np.testing.assert_allclose(np.asarray(c["2m_temperature"].values), ref["ens_2m_temperature"][i], rtol=0, atol=2e-6)
