@@ -713,7 +713,11 @@ def merge(objects: Sequence, compat: str = "no_conflicts", join: str = "outer", 
       raise ValueError("cannot merge an unnamed DataArray")
     for k, da in items.items():
       for ck, cv in da._coords.items():
-        if ck in coords and compat != "override" and not coords[ck].equals(cv):
+        is_index = cv.dims == (ck,)          # a dimension coordinate: what `join` aligns on
+        if ck in coords and is_index and not coords[ck].equals(cv):
+          raise ValueError(f"cannot align objects with join='exact' where index/labels/sizes are "
+                           f"not equal along dimension {ck!r}")
+        if ck in coords and not is_index and compat != "override" and not coords[ck].equals(cv):
           raise ValueError(f"conflicting values for coordinate {ck!r}")
         if ck in coords and coords[ck].shape != cv.shape:
           raise ValueError(f"cannot align objects with join='exact' along {ck!r}")

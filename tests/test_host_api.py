@@ -480,3 +480,45 @@ def test_xarray_lite_label_selection_squeeze_expand_update():
   assert same is ds and "b" in ds.data_vars and ds["b"].dims == ("time",)
   shifted = ds.coords["time"] + pd.Timedelta("6h") - ds.coords["time"][-1]
   assert shifted.values[-1] == np.timedelta64(6, "h")
+
+
+def test_xarray_tree_map_structure_reference_cases():
+  """The six cases of the reference's xarray_tree_test.py, restated."""
+  from graphcast_amd import xarray_lite as xl
+  from graphcast_amd import xarray_tree
+  ds = xl.Dataset(data_vars={"foo": (("x", "y"), np.zeros((2, 3))), "bar": (("x",), np.zeros((2,)))},
+                  coords={"x": [1, 2], "y": [10, 20, 30]})
+
+  def plus_one_unnamed(leaf):                                          # :36-48
+    assert isinstance(leaf, xl.DataArray)
+    return (leaf + 1).rename(None)
+  out = xarray_tree.map_structure(plus_one_unnamed, ds)
+  assert isinstance(out, xl.Dataset) and set(out.keys()) == {"foo", "bar"}
+  np.testing.assert_array_equal(out["foo"].values, np.ones((2, 3)))
+
+  out = xarray_tree.map_structure(lambda x: x + 1, dict(ds))         # :50-54
+  assert isinstance(out, dict) and set(out) == {"foo", "bar"}
+
+  def incompatible(leaf):                                              # :56-70
+    coords = {"x": [1, 2]} if leaf.name == "foo" else {"x": [3, 4]}
+    return xl.DataArray(data=np.zeros(2), dims=("x",), coords=coords)
+  out = xarray_tree.map_structure(incompatible, ds)
+  assert isinstance(out, dict) and set(out) == {"foo", "bar"}
+
+  out = xarray_tree.map_structure(lambda leaf: leaf if leaf.name == "foo" else None, ds)   # :72-79
+  assert isinstance(out, xl.Dataset) and set(out.keys()) == {"foo"}
+
+  out = xarray_tree.map_structure(lambda leaf: "not a DataArray", ds)                     # :81-88
+  assert out == {"foo": "not a DataArray", "bar": "not a DataArray"}
+
+  seen = []
+  xarray_tree.map_structure(lambda a, b: seen.append((a.name, b.name)), ds, ds[["bar", "foo"]])   # :90-94
+  assert seen and all(a == b for a, b in seen)
+
+  # nested containers, and argument checks
+  nested = xarray_tree.map_structure(lambda a: a * 2, {"k": [ds["foo"], (ds["bar"],)]})
+  assert isinstance(nested["k"], list) and isinstance(nested["k"][1], tuple)
+  with pytest.raises(TypeError):
+    xarray_tree.map_structure("nope", ds)
+  with pytest.raises(ValueError):
+    xarray_tree.map_structure(lambda x: x)
