@@ -109,3 +109,67 @@ def test_plan_api_argument_checks_without_gpu(lib):
   t = (nat.TensorDesc * 1)(nat.TensorDesc(b"x/w", None, 1, 1))
   assert lib.gc_plan_create(ctypes.byref(m), t, 1, None, ctypes.byref(handle)) == -1
   assert b"gc_plan_create" in lib.gc_last_error()
+
+
+# ---- property tests (hypothesis): random graphs / matrices, C++ packers == numpy packers ----------
+hypothesis = pytest.importorskip("hypothesis")
+from hypothesis import given, settings, strategies as st          # noqa: E402
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 60), st.integers(1, 400), st.integers(0, 2 ** 31 - 1), st.booleans())
+def test_property_pack_edges_native_equals_numpy(n_recv, n_edges, seed, uniform):
+  rng = np.random.default_rng(seed)
+  lib = nat.lib()
+  if uniform:                      # every receiver the same degree (exercises the padded-tile layout)
+    deg = int(rng.integers(1, 9))
+    receivers = rng.permutation(np.repeat(np.arange(n_recv), deg)).astype(np.int32)
+  else:
+    receivers = rng.integers(0, n_recv, n_edges).astype(np.int32)
+  senders = rng.integers(0, 50, len(receivers)).astype(np.int32)
+  want = packing.pack_edges(senders, receivers, n_recv)
+  cap = 64 * (len(receivers) // 21 + 1)
+  perm, snd, rcv = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+  flags, fix, empty = np.empty(cap // 64, np.int32), np.empty(3 * n_recv, np.int32), np.empty(n_recv, np.int32)
+  n_fix, n_empty = ctypes.c_int(), ctypes.c_int()
+  n_rows = lib.gc_host_pack_edges(len(receivers), senders.ctypes.data, receivers.ctypes.data, n_recv,
+                                  perm.ctypes.data, snd.ctypes.data, rcv.ctypes.data, flags.ctypes.data,
+                                  fix.ctypes.data, ctypes.byref(n_fix), empty.ctypes.data, ctypes.byref(n_empty))
+  assert n_rows == want.n_rows <= cap
+  np.testing.assert_array_equal(perm[:n_rows], want.perm)
+  np.testing.assert_array_equal(snd[:n_rows], want.senders)
+  np.testing.assert_array_equal(rcv[:n_rows], want.receivers)
+  np.testing.assert_array_equal(flags[:n_rows // 64], want.tile_flags)
+  np.testing.assert_array_equal(fix[:3 * n_fix.value].reshape(-1, 3)[:, 0], want.fix_recv)
+  np.testing.assert_array_equal(empty[:n_empty.value], want.empty_receivers)
+  # invariants of the packed order itself: a permutation of the edges, receiver-sorted, padding trails
+  ok = want.perm >= 0
+  assert sorted(want.perm[ok]) == list(range(len(receivers)))
+  assert (np.diff(want.receivers[ok]) >= 0).all()
+  for t in range(n_rows // 64):
+    tile = want.perm[64 * t:64 * t + 64] >= 0
+    assert not (np.diff(tile.astype(int)) > 0).any()          # once padding starts, it stays
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(1, 70), st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.sampled_from(["f32", "f16x3", "bf16"]),
+       st.booleans(), st.floats(1e-4, 30.0))
+def test_property_pack_weight_native_equals_numpy(k, n, seed, prec, chained, magnitude):
+  rng = np.random.default_rng(seed)
+  lib = nat.lib()
+  w = (magnitude * rng.standard_normal((k, n))).astype(np.float32)
+  np_cols = 64
+  if prec == "f32":
+    want, want_scale = packing.pack_weight(w, np_cols=np_cols), 1.0
+    chained = False
+  elif prec == "f16x3":
+    want_scale = packing.choose_weight_scale(w)
+    want = packing.pack_weight_split(w, np_cols=np_cols, chained=chained, scale=want_scale)
+  else:
+    want, want_scale = packing.pack_weight_bf16(w, np_cols=np_cols, chained=chained), 1.0
+  scale = ctypes.c_float(0)
+  got = np.empty(want.nbytes, dtype=np.uint8)
+  assert lib.gc_host_pack_weight(nat.PRECISIONS[prec], int(chained), w.ctypes.data, k, n, np_cols,
+                                 got.ctypes.data, ctypes.byref(scale)) == want.nbytes
+  assert scale.value == want_scale
+  np.testing.assert_array_equal(got, np.ascontiguousarray(want).view(np.uint8).ravel())
