@@ -53,36 +53,77 @@ def _node_features(phi, theta, num_nodes, dtype, add_node_positions, add_node_la
   return np.stack(feats, axis=-1)
 
 
-def _relative_positions(s_phi, s_theta, r_phi, r_theta, senders, receivers,
-                        latitude_local_coordinates, longitude_local_coordinates):
-  """sender - receiver position in the receiver's rotated frame, float64 [E, 3]."""
-  s_pos = np.stack(spherical_to_cartesian(s_phi, s_theta), axis=-1)
-  r_pos = np.stack(spherical_to_cartesian(r_phi, r_theta), axis=-1)
+def get_rotation_matrices_to_local_coordinates(reference_phi: np.ndarray, reference_theta: np.ndarray,
+                                               rotate_latitude: bool, rotate_longitude: bool) -> np.ndarray:
+  """[N, 3, 3] float64 matrices M such that ``rotate_with_matrices(M, p)`` takes the reference
+  point to longitude 0 (``rotate_longitude``) and / or latitude 0, i.e. polar angle pi/2
+  (``rotate_latitude``) -- reference model_utils.py:322-395.  With a = -phi and b = pi/2 - theta:
+    longitude only       p -> Rz(a) p
+    both                 p -> Ry(b) Rz(a) p
+    latitude only        p -> Rz(-a) Ry(b) Rz(a) p   (keeps the point's own longitude)
+  Built from the closed forms of Rz / Ry (the reference asks scipy for the same rotations; the
+  angles are promoted to float64 exactly as scipy does)."""
+  if not (rotate_latitude or rotate_longitude):
+    raise ValueError("At least one of longitude and latitude should be rotated.")
+  a = (-np.asarray(reference_phi)).astype(np.float64)
+  b = (-np.asarray(reference_theta) + np.pi / 2).astype(np.float64)
+  zero, one = np.zeros_like(a), np.ones_like(a)
+
+  def rz(t):
+    c, s = np.cos(t), np.sin(t)
+    return np.stack([np.stack([c, -s, zero], -1), np.stack([s, c, zero], -1), np.stack([zero, zero, one], -1)], -2)
+
+  def ry(t):
+    c, s = np.cos(t), np.sin(t)
+    return np.stack([np.stack([c, zero, s], -1), np.stack([zero, one, zero], -1), np.stack([-s, zero, c], -1)], -2)
+
+  if rotate_longitude and rotate_latitude:
+    forward = ry(b) @ rz(a)
+  elif rotate_longitude:
+    forward = rz(a)
+  else:
+    forward = rz(-a) @ ry(b) @ rz(a)
+  return forward
+
+
+def rotate_with_matrices(rotation_matrices: np.ndarray, positions: np.ndarray) -> np.ndarray:
+  """Batched M p: out[..., j] = sum_i M[..., j, i] p[..., i] (reference model_utils.py:401-403)."""
+  return np.einsum("...ji,...i->...j", rotation_matrices, positions)
+
+
+def get_relative_position_in_receiver_local_coordinates(
+    node_phi: np.ndarray, node_theta: np.ndarray, senders: np.ndarray, receivers: np.ndarray,
+    latitude_local_coordinates: bool, longitude_local_coordinates: bool) -> np.ndarray:
+  """[E, 3] sender - receiver positions, each edge in its receiver's rotated frame
+  (reference model_utils.py:237-319)."""
+  return get_bipartite_relative_position_in_receiver_local_coordinates(
+      node_phi, node_theta, senders, node_phi, node_theta, receivers,
+      latitude_local_coordinates, longitude_local_coordinates)
+
+
+def get_bipartite_relative_position_in_receiver_local_coordinates(
+    senders_node_phi: np.ndarray, senders_node_theta: np.ndarray, senders: np.ndarray,
+    receivers_node_phi: np.ndarray, receivers_node_theta: np.ndarray, receivers: np.ndarray,
+    latitude_local_coordinates: bool, longitude_local_coordinates: bool) -> np.ndarray:
+  """Bipartite form (reference model_utils.py:547-642): sender and receiver nodes come from
+  different sets; the frame is always the receiver's."""
+  s_pos = np.stack(spherical_to_cartesian(senders_node_phi, senders_node_theta), axis=-1)
+  r_pos = np.stack(spherical_to_cartesian(receivers_node_phi, receivers_node_theta), axis=-1)
   if not (latitude_local_coordinates or longitude_local_coordinates):
     return s_pos[senders] - r_pos[receivers]
-  # Rotation angles keep the reference's dtype path: computed in the node dtype,
-  # then promoted (scipy promotes euler angles to float64).
-  azimuth = (-r_phi).astype(np.float64)[receivers]
-  polar = (-r_theta + np.pi / 2).astype(np.float64)[receivers]
-  ca, sa = np.cos(azimuth), np.sin(azimuth)
-  cp, sp = np.cos(polar), np.sin(polar)
+  # one matrix per RECEIVER node, gathered per edge
+  m = get_rotation_matrices_to_local_coordinates(
+      receivers_node_phi, receivers_node_theta, rotate_latitude=latitude_local_coordinates,
+      rotate_longitude=longitude_local_coordinates)[receivers]
+  return (rotate_with_matrices(m, s_pos[senders].astype(np.float64))
+          - rotate_with_matrices(m, r_pos[receivers].astype(np.float64)))
 
-  def rot_z(p, c, s):       # Rz(angle) p
-    return np.stack([c * p[:, 0] - s * p[:, 1], s * p[:, 0] + c * p[:, 1], p[:, 2]], axis=-1)
 
-  def rot_y(p, c, s):       # Ry(angle) p
-    return np.stack([c * p[:, 0] + s * p[:, 2], p[:, 1], -s * p[:, 0] + c * p[:, 2]], axis=-1)
-
-  def to_local(p):
-    p = p.astype(np.float64)
-    if longitude_local_coordinates and latitude_local_coordinates:
-      return rot_y(rot_z(p, ca, sa), cp, sp)
-    if longitude_local_coordinates:
-      return rot_z(p, ca, sa)
-    # latitude only: to longitude 0, polar rotation, back to the original longitude
-    return rot_z(rot_y(rot_z(p, ca, sa), cp, sp), ca, -sa)
-
-  return to_local(s_pos[senders]) - to_local(r_pos[receivers])
+def _relative_positions(s_phi, s_theta, r_phi, r_theta, senders, receivers,
+                        latitude_local_coordinates, longitude_local_coordinates):
+  return get_bipartite_relative_position_in_receiver_local_coordinates(
+      s_phi, s_theta, senders, r_phi, r_theta, receivers,
+      latitude_local_coordinates, longitude_local_coordinates)
 
 
 def _edge_features(relative_position, num_edges, dtype, edge_normalization_factor):

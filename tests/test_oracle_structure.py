@@ -134,3 +134,31 @@ def test_1deg_structure_fingerprints(hashes):
 @pytest.mark.slow
 def test_0p25deg_structure_fingerprints(hashes):
   _check_against_hashes(hashes["0p25deg_M6"], 0.25, 6)
+
+
+def test_local_coordinate_helpers_match_reference_functions(golden_dir):
+  """get_rotation_matrices_to_local_coordinates, rotate_with_matrices,
+  get_relative_position_in_receiver_local_coordinates (+ bipartite) against the outputs of the
+  reference's own functions (tests/golden/make_golden_rotations.py -> rotation_ref.npz)."""
+  import os
+  from graphcast_amd import model_utils as mu
+  z = np.load(os.path.join(golden_dir, "rotation_ref.npz"))
+  for lat, lon in ((True, True), (False, True), (True, False)):
+    tag = f"lat{int(lat)}lon{int(lon)}"
+    m = mu.get_rotation_matrices_to_local_coordinates(z["phi"], z["theta"], rotate_latitude=lat, rotate_longitude=lon)
+    assert m.shape == (9, 3, 3) and m.dtype == np.float64
+    np.testing.assert_allclose(m, z[f"mat_{tag}"], atol=1e-15)
+    np.testing.assert_allclose(mu.rotate_with_matrices(m, z["pos"]), z[f"rot_{tag}"], atol=1e-14)
+    rel = mu.get_relative_position_in_receiver_local_coordinates(
+        z["phi"], z["theta"], z["senders"], z["receivers"], latitude_local_coordinates=lat, longitude_local_coordinates=lon)
+    np.testing.assert_allclose(rel, z[f"rel_{tag}"], atol=1e-14)
+    brel = mu.get_bipartite_relative_position_in_receiver_local_coordinates(
+        z["phi"], z["theta"], z["b_send"], z["phi2"], z["theta2"], z["b_recv"],
+        latitude_local_coordinates=lat, longitude_local_coordinates=lon)
+    np.testing.assert_allclose(brel, z[f"brel_{tag}"], atol=1e-14)
+  # the rotated receiver sits at longitude 0 / polar angle pi/2
+  m = mu.get_rotation_matrices_to_local_coordinates(z["phi"], z["theta"], rotate_latitude=True, rotate_longitude=True)
+  p = np.stack(mu.spherical_to_cartesian(z["phi"].astype(np.float64), z["theta"].astype(np.float64)), axis=-1)
+  np.testing.assert_allclose(mu.rotate_with_matrices(m, p), np.tile([1.0, 0.0, 0.0], (9, 1)), atol=1e-6)
+  with pytest.raises(ValueError):
+    mu.get_rotation_matrices_to_local_coordinates(z["phi"], z["theta"], rotate_latitude=False, rotate_longitude=False)
