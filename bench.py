@@ -90,7 +90,7 @@ def op_flops(op, c_out_exec=240):
   return f
 
 
-def _time_oracle(cfg_name, c_in, c_out, steps):
+def _time_oracle(cfg_name, c_in, c_out, steps, backend="numpy"):
   from oracle import graphcast as ogc
   res, mesh_size, _, _ = CONFIGS[cfg_name]
   lat = np.arange(-90, 90 + res / 2, res)
@@ -99,7 +99,11 @@ def _time_oracle(cfg_name, c_in, c_out, steps):
   params = fast_params(c_in, c_out, steps)
   x = np.random.default_rng(0).standard_normal((graphs["n_grid"], 1, c_in)).astype(np.float32)
   t0 = time.perf_counter()
-  ogc.forward(params, graphs, x, steps=steps, dtype=np.float32)
+  if backend == "torch":
+    from oracle import torch_cpu
+    torch_cpu.forward(params, graphs, x, steps)
+  else:
+    ogc.forward(params, graphs, x, steps=steps, dtype=np.float32)
   dt = time.perf_counter() - t0
   f_sample = flops_as_written(graphs["n_grid"], graphs["n_mesh"], len(graphs["g2m"]["senders"]),
                               len(graphs["mesh"]["senders"]), len(graphs["m2g"]["senders"]),
@@ -108,30 +112,41 @@ def _time_oracle(cfg_name, c_in, c_out, steps):
 
 
 def cpu_baseline(c_in, c_out, steps, f_full, budget_s=30.0):
-  """Times the numpy oracle (fp32 restatement of the reference step; JAX is not installable)
-  on the host cores, on a BOUNDED sample: the same architecture (0.25deg/37L channel widths,
-  `steps` processor steps) on a coarser grid/mesh.  The 4deg/M3 sample always runs; the
-  larger samples only run if the measured rate predicts they fit the time budget."""
+  """Times the CPU restatement of the reference step (fp32; JAX is not installable) on the host
+  cores, on a BOUNDED sample: the same architecture (0.25deg/37L channel widths, `steps` processor
+  steps) on a coarser grid/mesh.  The 4deg/M3 sample always runs; the larger samples only run if
+  the measured rate predicts they fit the time budget.  Executed with torch's CPU kernels on all
+  cores (oracle/torch_cpu.py, pinned to the numpy oracle by tests/test_oracle_torch_cpu.py) --
+  numpy's elementwise ops are single-threaded, which would understate a many-core host; the
+  numpy oracle is the fallback if torch's CPU path is unavailable."""
+  backend, threads = "torch", os.cpu_count() or 1
   try:
-    from threadpoolctl import threadpool_info
-    threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-  except Exception:                                     # pragma: no cover
-    threads = os.cpu_count() or 1
+    import torch
+    torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
+    _time_oracle("4deg_13L_M3", c_in, c_out, steps, backend)            # warm-up (thread pools, first touch)
+  except Exception:                                                      # pragma: no cover
+    backend = "numpy"
+    try:
+      from threadpoolctl import threadpool_info
+      threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+      threads = os.cpu_count() or 1
   used = "4deg_13L_M3"
-  dt, f_sample, mesh_size = _time_oracle(used, c_in, c_out, steps)
+  dt, f_sample, mesh_size = _time_oracle(used, c_in, c_out, steps, backend)
   for bigger, approx_tflop in (("2deg_13L_M4", 1.0), ("1deg_13L_M5", 4.2)):
     predicted = dt * approx_tflop * 1e12 / f_sample
     if predicted > budget_s:
       break
     used = bigger
-    dt, f_sample, mesh_size = _time_oracle(used, c_in, c_out, steps)
+    dt, f_sample, mesh_size = _time_oracle(used, c_in, c_out, steps, backend)
   est_full = dt * f_full / f_sample
   return {
       "value": 1.0 / est_full, "unit": "steps/s", "cores": threads, "kind": "port",
-      "sample": (f"numpy fp32 restatement of the reference step (JAX not installable) with the "
+      "sample": (f"{backend}-CPU fp32 restatement of the reference step (JAX not installable) with the "
                  f"0.25deg/37L channel widths on the {used.split('_')[0]}/M{mesh_size} graph: "
                  f"{f_sample / 1e12:.2f} TFLOP (as written) in {dt:.1f} s = "
-                 f"{f_sample / dt / 1e9:.0f} GFLOP/s on {threads} BLAS threads; scaled by the "
+                 f"{f_sample / dt / 1e9:.0f} GFLOP/s on {threads} threads; scaled by the "
                  f"as-written FLOP ratio {f_full / f_sample:.1f} to one 0.25deg step "
                  f"({est_full:.0f} s)"),
       "sample_seconds": dt}
