@@ -12,8 +12,8 @@ members never interact in the forward pass, reference rollout.py:220-283), so
 scaling is weak and `value` = N*K / max-over-ranks time.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
-objects: `roofline` for the dominant kernel and `cpu_baseline` (the numpy oracle
-timed on the host cores on a bounded sample, N = 1 only).
+objects: `roofline` for the dominant kernel and `cpu_baseline` (the oracle's CPU restatement,
+on torch's CPU kernels, timed on the host cores on a bounded sample, N = 1 only).
 """
 import argparse
 import json
