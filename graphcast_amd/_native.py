@@ -14,8 +14,8 @@ _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
 OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
-PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
-PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
+PREC_F32, PREC_F16X3, PREC_BF16_GEMM = 0, 1, 2
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16gemm": PREC_BF16_GEMM}
 LAYOUT_CHUNKED, LAYOUT_COLOWN = 0, 1
 LATENT = 512
 TILE_ROWS = 64

@@ -974,12 +974,12 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
 
 #include "rowmlp_colown.inc"
 
-// ---- GC_PREC_BF16 -----------------------------------------------------------------------
-// The tier the published GraphCast demo runs (casting.Bfloat16Cast, utils/casting.py:31-65): GEMM
-// operands rounded to bfloat16 (round to nearest even), ONE v_mfma_f32_16x16x32_bf16 per product,
-// fp32 accumulation.  Everything between the GEMMs (bias, addends, swish, LayerNorm, residual,
-// segment-sum) stays fp32 here -- more precise than the reference's all-bf16 activations, so this
-// is NOT the fp32-tolerance path; it is checked against an oracle that rounds the same operands.
+// ---- GC_PREC_BF16_GEMM -----------------------------------------------------------------------
+// A reduced-precision tier: GEMM operands rounded to bfloat16 (round to nearest even), ONE
+// v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation.  Everything between the GEMMs (bias,
+// addends, swish, LayerNorm, residual, segment-sum) stays fp32 -- so this is neither the
+// fp32-tolerance path nor the numerics of the reference's Bfloat16Cast (utils/casting.py:45-65: all
+// activations in bfloat16, not built); it is checked against an oracle that rounds the same operands.
 // Same register-chained structure as the split-f16 kernel, half the LDS image (no lo halves),
 // groups of eight n-blocks so that eight MFMAs still cover the next group's fragment reads.
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
@@ -1344,7 +1344,7 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   const int split = d.prec;      // 0 f32, 1 f16x3, 2 bf16
   if (!g_attr_set[split][MODE]) {
     const void* fn = split == GC_PREC_F16X3 ? reinterpret_cast<const void*>(&rowmlp16_kernel<MODE>)
-                     : split == GC_PREC_BF16 ? reinterpret_cast<const void*>(&rowmlpb_kernel<MODE>)
+                     : split == GC_PREC_BF16_GEMM ? reinterpret_cast<const void*>(&rowmlpb_kernel<MODE>)
                                              : reinterpret_cast<const void*>(&rowmlp_kernel<MODE>);
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -1356,7 +1356,7 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
   if (split == GC_PREC_F16X3) {
     hipLaunchKernelGGL(rowmlp16_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
-  } else if (split == GC_PREC_BF16) {
+  } else if (split == GC_PREC_BF16_GEMM) {
     hipLaunchKernelGGL(rowmlpb_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
   } else {
     hipLaunchKernelGGL(rowmlp_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
@@ -1404,7 +1404,7 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
     return fail(GC_EINVAL, "gc_rowmlp: weight scales are not a GC_PREC_F32 feature");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
-  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16)
+  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16_GEMM)
     return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
   if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_COLOWN)
     return fail(GC_EINVAL, "gc_rowmlp: unknown weight layout");

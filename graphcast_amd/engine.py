@@ -31,8 +31,9 @@ D = packing.LATENT
 
 # Arithmetic of the GEMMs (include/gcast.h `gc_precision`): "f16x3" = fp32 operands split into
 # two halves in registers, three f16 MFMAs per product, fp32 accumulation (fp32-grade results);
-# "f32" = exact fp32 MFMA; "bf16" = the reduced-precision tier of the reference's Bfloat16Cast
-# (GEMM operands rounded to bfloat16; NOT within the fp32 tolerance).  Overridable with
+# "f32" = exact fp32 MFMA; "bf16gemm" = a reduced-precision tier (GEMM operands rounded to bfloat16,
+# fp32 everywhere else; NOT within the fp32 tolerance and NOT the numerics of the reference's
+# Bfloat16Cast, see casting.py).  Overridable with
 # GCAST_PRECISION.
 DEFAULT_PRECISION = "f16x3"
 
@@ -83,7 +84,7 @@ class _Mlp:
               if colown and np_cols == D else None)
         return _PW(up(packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc)
                       .view(np.int16)), sc, co)
-    elif prec == nat.PREC_BF16:
+    elif prec == nat.PREC_BF16_GEMM:
       pack1 = lambda w: _PW(up(packing.pack_weight_bf16(w).view(np.int16)))
       pack2 = lambda w, np_cols: _PW(up(packing.pack_weight_bf16(w, np_cols=np_cols, chained=True)
                                        .view(np.int16)))
@@ -430,6 +431,16 @@ class StepEngine:
     return y
 
   __call__ = forward
+
+  def run_until(self, x: torch.Tensor, tag: str, y: Optional[torch.Tensor] = None):
+    """Enqueues the step's launches up to (not including) the first launch tagged `tag` (batch
+    element 0) and returns how many ran: the workspace then holds that stage boundary -- e.g.
+    `run_until(x, "enc_node_mesh")` leaves the encoder's grid2mesh aggregate in `agg_mesh`.
+    Verification hook (tests compare stage boundaries with the oracle); not on the product path."""
+    arr, _ = self.bind(x, y)
+    n = next(k for k in range(len(arr)) if arr[k].tag == TAGS[tag])
+    nat.check(self.lib.gc_run_program(arr, n, self._stream_ptr()), "gc_run_program")
+    return n
 
   # ---------------------------------------------------------------- partitioned execution
   def segments(self, x: torch.Tensor, y: Optional[torch.Tensor] = None):

@@ -98,7 +98,14 @@ class GraphCast(predictor_base.Predictor):
 
   def __init__(self, model_config: ModelConfig, task_config: TaskConfig,
                params: Optional[Mapping[str, Mapping[str, Any]]] = None, device: str = "cuda:0",
-               precision: Optional[str] = None, colown: Optional[bool] = None):
+               precision: Optional[str] = None, colown: Optional[bool] = None,
+               mesh2grid_face_indices=None):
+    """``mesh2grid_face_indices``: optional precomputed answer of the reference's
+    ``trimesh.Trimesh(...).nearest.on_surface`` query (``utils/legacy/grid_mesh_connectivity.py:
+    114-119``) -- the finest-mesh face id containing each grid point, ``[n_lat * n_lon]`` ints in
+    grid-node order, as an array or the path of a ``.npy`` file.  A host that has trimesh can
+    supply the reference's exact choice (it only matters for the grid points lying exactly on a
+    mesh edge: 254 at 0.25 deg); without it the restated rule of grid_mesh_connectivity.py runs."""
     if model_config.hidden_layers != 1:
       raise NotImplementedError("the MI355X build fuses exactly one hidden layer per MLP "
                                 "(hidden_layers=1, the value of every published GraphCast)")
@@ -120,6 +127,10 @@ class GraphCast(predictor_base.Predictor):
                           * model_config.radius_query_fraction_edge_length)
     self._mesh2grid_edge_normalization_factor = model_config.mesh2grid_edge_normalization_factor
     self._params = params
+    if isinstance(mesh2grid_face_indices, (str, bytes)) or hasattr(mesh2grid_face_indices, "__fspath__"):
+      mesh2grid_face_indices = np.load(mesh2grid_face_indices)
+    self._mesh2grid_face_indices = (None if mesh2grid_face_indices is None
+                                    else np.asarray(mesh2grid_face_indices))
     self._initialized = False
     self._engine = None
     self._engines = {}
@@ -134,7 +145,7 @@ class GraphCast(predictor_base.Predictor):
     self._engines = {}
 
   def set_precision(self, precision: Optional[str]) -> Optional[str]:
-    """Selects the GEMM arithmetic ("f16x3" | "f32" | "bf16", None = default); returns the
+    """Selects the GEMM arithmetic ("f16x3" | "f32" | "bf16gemm", None = default); returns the
     previous setting.  Engines are cached per precision (each holds its own packed weights)."""
     prev = self._precision
     if precision != prev:
@@ -219,7 +230,8 @@ class GraphCast(predictor_base.Predictor):
 
   def _init_mesh2grid_graph(self) -> typed_graph.TypedGraph:
     grid_indices, mesh_indices = grid_mesh_connectivity.in_mesh_triangle_indices(
-        grid_latitude=self._grid_lat, grid_longitude=self._grid_lon, mesh=self._finest_mesh)
+        grid_latitude=self._grid_lat, grid_longitude=self._grid_lon, mesh=self._finest_mesh,
+        query_face_indices=self._mesh2grid_face_indices)
     s_feat, r_feat, e_feat = model_utils.get_bipartite_graph_spatial_features(
         senders_node_lat=self._mesh_nodes_lat, senders_node_lon=self._mesh_nodes_lon,
         receivers_node_lat=self._grid_nodes_lat, receivers_node_lon=self._grid_nodes_lon,

@@ -101,10 +101,24 @@ def _nearest_face_on_surface(points: np.ndarray, mesh: icosahedral_mesh.Triangul
 
 
 def in_mesh_triangle_indices(*, grid_latitude: np.ndarray, grid_longitude: np.ndarray,
-                             mesh: icosahedral_mesh.TriangularMesh) -> Tuple[np.ndarray, np.ndarray]:
-  """3 edges per grid point: the vertices of the mesh face nearest to it -> that grid point."""
+                             mesh: icosahedral_mesh.TriangularMesh,
+                             query_face_indices=None) -> Tuple[np.ndarray, np.ndarray]:
+  """3 edges per grid point: the vertices of the mesh face nearest to it -> that grid point.
+
+  ``query_face_indices`` (optional, ``[n_lat * n_lon]`` ints): the face per grid point computed
+  elsewhere -- e.g. by the reference's own ``trimesh`` query (reference :114-119) on a host that has
+  it -- used instead of the restated nearest-face rule; validated for shape and range."""
   grid_positions = _grid_lat_lon_to_coordinates(grid_latitude, grid_longitude).reshape([-1, 3])
-  query_face_indices = _nearest_face_on_surface(grid_positions, mesh)
+  if query_face_indices is None:
+    query_face_indices = _nearest_face_on_surface(grid_positions, mesh)
+  else:
+    query_face_indices = np.asarray(query_face_indices)
+    if (query_face_indices.shape != (grid_positions.shape[0],)
+        or not np.issubdtype(query_face_indices.dtype, np.integer)):
+      raise ValueError(f"query_face_indices must be {grid_positions.shape[0]} integers (one face per "
+                       f"grid point, lat-major), got {query_face_indices.dtype}{query_face_indices.shape}")
+    if query_face_indices.min() < 0 or query_face_indices.max() >= len(mesh.faces):
+      raise ValueError(f"query_face_indices out of range [0, {len(mesh.faces)})")
   mesh_edge_indices = mesh.faces[query_face_indices].reshape([-1])
   grid_edge_indices = np.repeat(np.arange(grid_positions.shape[0]), 3)
   return grid_edge_indices, mesh_edge_indices

@@ -42,33 +42,102 @@ class PredictorFn(Protocol):
 
 
 # ----------------------------------------------------------------------------- rng
-def split_rng(rng):
-  """(carry, this_step) -- the role of ``_split_rng_fn`` (reference :568-578)."""
+def split_rng(rng, split_fn: Optional[Callable[[Any], tuple]] = None):
+  """(carry, key for this chunk) -- the role of ``_split_rng_fn`` (reference :568-578).
+
+  ``None`` stays ``None`` (deterministic predictors); ints, integer key arrays and
+  ``SeedSequence`` spawn two child SeedSequences; a ``numpy.random.Generator`` spawns two child
+  generators; any other key type needs the caller's
+  own ``split_fn(key) -> (carry, this)`` (e.g. ``lambda k: tuple(jax.random.split(k))``) -- handing
+  the SAME opaque key to every chunk would correlate the noise across lead times."""
   if rng is None:
     return None, None
+  if split_fn is not None:
+    carry, this = split_fn(rng)
+    return carry, this
   if isinstance(rng, (int, np.integer)):
     rng = np.random.SeedSequence(int(rng))
-  if isinstance(rng, np.random.SeedSequence):
-    a, b = rng.spawn(2)
-    return a, b
-  return rng, rng        # opaque key owned by the caller's predictor
+  elif isinstance(rng, np.ndarray) and rng.dtype.kind in "ui":
+    # a raw key array (the layout of a jax PRNGKey): its words seed a SeedSequence
+    rng = np.random.SeedSequence([int(w) for w in rng.reshape(-1)])
+  if isinstance(rng, (np.random.SeedSequence, np.random.Generator)):
+    carry, this = rng.spawn(2)
+    return carry, this
+  raise TypeError(f"cannot split an rng of type {type(rng).__name__}: pass None, an int, an integer "
+                  "key array, a numpy SeedSequence / Generator, or rng_split_fn=")
 
 
 # ----------------------------------------------------------------------------- next inputs
 def _get_next_inputs(prev_inputs: xarray.Dataset, next_frame: xarray.Dataset) -> xarray.Dataset:
-  """Rolling window: drop the oldest frame, append the new one (reference :581-604)."""
-  non_predicted_or_forced_inputs = [k for k in prev_inputs.keys() if k not in next_frame.keys()]
-  for k in non_predicted_or_forced_inputs:
-    if "time" in prev_inputs[k].dims:
+  """The autoregressive window: same number of frames as before, advanced by the frames of
+  ``next_frame`` (predictions merged with the forcings of the times just predicted).  Inputs
+  without a time axis (statics) are carried over; an input WITH a time axis that is neither
+  predicted nor forced cannot be advanced (reference :581-604)."""
+  fed_back = set(next_frame.keys())
+  for name in prev_inputs.keys():
+    if name not in fed_back and "time" in prev_inputs[name].dims:
       raise ValueError("Found an input with a time index that is not predicted or forced.")
-  next_inputs_keys = [k for k in next_frame.keys() if k in prev_inputs.keys()]
-  next_inputs = next_frame[next_inputs_keys]
-  num_inputs = prev_inputs.sizes["time"]
-  return xarray.concat([prev_inputs, next_inputs], dim="time", data_vars="different",
-                       compat="equals").tail(time=num_inputs)
+  window = prev_inputs.sizes["time"]
+  newest = next_frame[[name for name in next_frame.keys() if name in prev_inputs.keys()]]
+  joined = xarray.concat([prev_inputs, newest], dim="time", data_vars="different", compat="equals")
+  return joined.tail(time=window)
 
 
 # ----------------------------------------------------------------------------- generator
+class _ChunkSchedule:
+  """What is fixed before the first step of a chunked rollout: validated chunking, the datasets
+  stripped of absolute ``datetime`` (the predictor sees lead times only), and the RELATIVE time
+  axes every chunk is presented with -- chunk k of the rollout looks to the predictor exactly
+  like chunk 0 (reference :421-463)."""
+
+  def __init__(self, inputs, targets_template, forcings, steps_per_chunk):
+    if forcings is None:
+      # (the reference iterates `.coords` keys here and cannot unpack them, SURVEY.md A.7)
+      forcings = xarray.Dataset({}, coords={
+          n: c for n, c in targets_template.coords.items() if "time" in c.dims})
+    self.template = self._without_datetime(targets_template)
+    self.forcings = self._without_datetime(forcings)
+    self.first_inputs = self._without_datetime(inputs)
+    self.datetime = targets_template.coords["datetime"] if "datetime" in targets_template.coords else None
+    total = self.template.sizes["time"]
+    self.steps_per_chunk = steps_per_chunk
+    self.num_chunks, leftover = divmod(total, steps_per_chunk)
+    if leftover != 0:
+      raise ValueError(
+          f"The number of steps per chunk {steps_per_chunk} must "
+          f"evenly divide the number of target steps {total} ")
+    lead = np.asarray(self.template.coords["time"].values)
+    if len(np.unique(np.diff(lead))) > 1:
+      raise ValueError("The targets time coordinates must be evenly spaced")
+    self.inputs_time = self.first_inputs.coords["time"].values
+    self.chunk_time = lead[:steps_per_chunk]
+
+  @staticmethod
+  def _without_datetime(ds):
+    ds = ds.copy()                         # never mutate the caller's datasets
+    if "datetime" in ds.coords:
+      del ds.coords["datetime"]
+    return ds
+
+  def rows(self, k):
+    return slice(k * self.steps_per_chunk, (k + 1) * self.steps_per_chunk)
+
+  def chunk(self, k, stage):
+    """(template, forcings) of chunk k, staged (replicated / moved to the device) and relabelled
+    with the first chunk's lead times, plus the true time-indexed coordinates of that chunk."""
+    template = self.template.isel(time=self.rows(k)).compute()
+    forcings = self.forcings.isel(time=self.rows(k)).compute()
+    true_coords = {n: c for n, c in template.coords.items() if "time" in c.dims}
+    relabel = lambda ds: stage(ds).assign_coords(time=self.chunk_time)
+    return relabel(template), relabel(forcings), true_coords
+
+  def stamp(self, predictions, k, true_coords):
+    predictions = predictions.assign_coords(true_coords)
+    if self.datetime is not None:
+      predictions.coords["datetime"] = self.datetime.isel(time=self.rows(k))
+    return predictions
+
+
 def chunked_prediction_generator(
     predictor_fn: PredictorFn,
     rng: Any,
@@ -81,8 +150,12 @@ def chunked_prediction_generator(
     replica_axis: Optional[str] = None,
     device_put_fn: Optional[Callable[[xarray.Dataset], xarray.Dataset]] = None,
     replicate_fn: Optional[Callable[[xarray.Dataset], xarray.Dataset]] = None,
+    rng_split_fn: Optional[Callable[[Any], tuple]] = None,
 ) -> Iterator[xarray.Dataset]:
-  """Yields the predictions of each chunk of a chunked rollout (reference :367-565)."""
+  """Yields the predictions of each chunk of a chunked rollout (reference :367-565).
+
+  ``rng_split_fn`` (not in the reference): how to split an rng key this module does not know
+  (see ``split_rng``)."""
   if pmap_devices is not None:
     raise ValueError(
         "pmap_devices is a single-process multi-device feature of the reference; this build runs "
@@ -90,88 +163,25 @@ def chunked_prediction_generator(
   if (replicate_fn is None) ^ (replica_axis is None):
     raise ValueError("Must provide replicate_fn when replica_axis is provided.")
 
-  if forcings is None:
-    # (the reference iterates `.coords` keys here and cannot unpack them)
-    forcings = xarray.Dataset({}, coords={
-        n: c for n, c in targets_template.coords.items() if "time" in c.dims})
-
-  # Copies: never mutate the caller's datasets.
-  inputs = inputs.copy()
-  targets_template = targets_template.copy()
-  forcings = forcings.copy()
-
-  if "datetime" in inputs.coords:
-    del inputs.coords["datetime"]
-  if "datetime" in targets_template.coords:
-    output_datetime = targets_template.coords["datetime"]
-    del targets_template.coords["datetime"]
-  else:
-    output_datetime = None
-  if "datetime" in forcings.coords:
-    del forcings.coords["datetime"]
-
-  num_target_steps = targets_template.sizes["time"]
-  num_chunks, remainder = divmod(num_target_steps, num_steps_per_chunk)
-  if remainder != 0:
-    raise ValueError(
-        f"The number of steps per chunk {num_steps_per_chunk} must "
-        f"evenly divide the number of target steps {num_target_steps} ")
-  if len(np.unique(np.diff(np.asarray(targets_template.coords["time"].values)))) > 1:
-    raise ValueError("The targets time coordinates must be evenly spaced")
-
-  # Every chunk is presented with the time coordinates of the first chunk.
-  chunk_inputs_time_array = inputs.coords["time"].values
-  chunk_targets_time_array = targets_template.isel(
-      time=slice(0, num_steps_per_chunk)).coords["time"].values
-
-  current_inputs = inputs
-  if replicate_fn is not None:
-    current_inputs = replicate_fn(current_inputs)
-  if device_put_fn is not None:
-    current_inputs = device_put_fn(current_inputs)
-  del inputs
-
-  for chunk_index in range(num_chunks):
-    if verbose:
-      log.info("Chunk %d/%d", chunk_index, num_chunks)
-    target_offset = num_steps_per_chunk * chunk_index
-    target_slice = slice(target_offset, target_offset + num_steps_per_chunk)
-    current_targets_template = targets_template.isel(time=target_slice).compute()
-    current_forcings = forcings.isel(time=target_slice).compute()
-
-    time_coords_to_override = {
-        n: c for n, c in current_targets_template.coords.items() if "time" in c.dims}
-
+  def stage(ds):
     if replicate_fn is not None:
-      current_forcings = replicate_fn(current_forcings)
-      current_targets_template = replicate_fn(current_targets_template)
-    if device_put_fn is not None:
-      current_forcings = device_put_fn(current_forcings)
-      current_targets_template = device_put_fn(current_targets_template)
+      ds = replicate_fn(ds)
+    return device_put_fn(ds) if device_put_fn is not None else ds
 
-    rng, this_rng = split_rng(rng)
-
-    current_inputs = current_inputs.assign_coords(time=chunk_inputs_time_array)
-    current_forcings = current_forcings.assign_coords(time=chunk_targets_time_array)
-    current_targets_template = current_targets_template.assign_coords(time=chunk_targets_time_array)
-    predictions = predictor_fn(
-        rng=this_rng, inputs=current_inputs, targets_template=current_targets_template,
-        forcings=current_forcings)
-    del current_targets_template
-
-    if chunk_index == num_chunks - 1:
-      current_inputs = None
-    else:
-      next_frame = predictions.assign(current_forcings)
-      current_inputs = _get_next_inputs(current_inputs, next_frame)
-      del next_frame
-    del current_forcings
-
-    predictions = predictions.assign_coords(time_coords_to_override)
-    if output_datetime is not None:
-      predictions.coords["datetime"] = output_datetime.isel(time=target_slice)
-    yield predictions
-    del predictions
+  schedule = _ChunkSchedule(inputs, targets_template, forcings, num_steps_per_chunk)
+  state = stage(schedule.first_inputs)          # the rolling input window; stays where `stage` put it
+  del inputs
+  for k in range(schedule.num_chunks):
+    if verbose:
+      log.info("Chunk %d/%d", k, schedule.num_chunks)
+    template_k, forcings_k, true_coords = schedule.chunk(k, stage)
+    rng, key = split_rng(rng, rng_split_fn)
+    state = state.assign_coords(time=schedule.inputs_time)
+    predictions = predictor_fn(rng=key, inputs=state, targets_template=template_k, forcings=forcings_k)
+    # feed back: what was just predicted plus the forcings valid at those times
+    state = (_get_next_inputs(state, predictions.assign(forcings_k))
+             if k + 1 < schedule.num_chunks else None)
+    yield schedule.stamp(predictions, k, true_coords)
 
 
 def _to_host(ds: xarray.Dataset) -> xarray.Dataset:

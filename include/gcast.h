@@ -65,13 +65,14 @@ extern "C" {
  *                 v_mfma_f32_16x16x32_f16 accumulating in fp32 (dropped term
  *                 ~2^-22): fp32-grade results at 1/3 of the 2.5 PF f16 MFMA
  *                 peak.  |x| must stay below 1.3e5 (saturating split).
- *   GC_PREC_BF16  the reduced-precision TIER the published GraphCast demo runs
- *                 (casting.Bfloat16Cast, utils/casting.py:31-65): GEMM operands rounded to
- *                 bfloat16 (nearest even), one v_mfma_f32_16x16x32_bf16 per product, fp32
- *                 accumulation; everything between the GEMMs stays fp32.  NOT within the fp32
- *                 tolerance of the path (~3e-3 rel-RMSE); weights packed as the hi-only image
+ *   GC_PREC_BF16_GEMM  a reduced-precision TIER: GEMM operands rounded to bfloat16 (nearest
+ *                 even), one v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; everything
+ *                 between the GEMMs stays fp32.  NOT within the fp32 tolerance of the path
+ *                 (~3e-3 rel-RMSE) and NOT the numerics of the reference's Bfloat16Cast
+ *                 (utils/casting.py:45-65 runs the activations in bfloat16 too -- not built);
+ *                 weights packed as the hi-only image
  *                 [NP/16 n-blocks][64 lanes][8 bf16] per 32-row K chunk (NP * 64 bytes). */
-enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16 = 2 };
+enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2 };
 
 /* How w1p / w2p are packed, i.e. which tile formulation runs.
  *   GC_LAYOUT_CHUNKED  the layouts described above: 32-row K chunks staged through LDS, every wave

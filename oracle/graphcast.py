@@ -15,8 +15,10 @@ import numpy as np
 from oracle import connectivity, features, gnn, mesh
 
 
-def build_graphs(lat, lon, mesh_size, radius_fraction=0.6, m2g_norm=None):
-  """Static structure: indices + structural features of the three graphs."""
+def build_graphs(lat, lon, mesh_size, radius_fraction=0.6, m2g_norm=None, m2g_face_indices=None):
+  """Static structure: indices + structural features of the three graphs.
+  `m2g_face_indices`: a given answer of the containing-face query (:114-119) instead of the
+  restated rule (one finest-mesh face id per grid point)."""
   lat = np.asarray(lat).astype(np.float32)
   lon = np.asarray(lon).astype(np.float32)
   levels = mesh.mesh_hierarchy(mesh_size)
@@ -31,7 +33,11 @@ def build_graphs(lat, lon, mesh_size, radius_fraction=0.6, m2g_norm=None):
   g2m_feat, _ = features.edge_features(g_lat, g_lon, m_lat, m_lon, g2m_grid, g2m_mesh)
   ms, mr = mesh.faces_to_edges(mesh.merged_faces(levels))
   mesh_feat, _ = features.edge_features(m_lat, m_lon, m_lat, m_lon, ms, mr)
-  m2g_grid, m2g_mesh = connectivity.containing_triangle_query(lat, lon, verts, faces)
+  if m2g_face_indices is None:
+    m2g_grid, m2g_mesh = connectivity.containing_triangle_query(lat, lon, verts, faces)
+  else:
+    m2g_mesh = np.asarray(faces)[np.asarray(m2g_face_indices)].reshape([-1])
+    m2g_grid = np.repeat(np.arange(len(g_lat)), 3)
   m2g_feat, _ = features.edge_features(m_lat, m_lon, g_lat, g_lon, m2g_mesh, m2g_grid,
                                        normalization=m2g_norm)
   return dict(

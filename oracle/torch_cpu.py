@@ -7,6 +7,8 @@ TEST INFRASTRUCTURE like the rest of oracle/: it exists so that bench.py's `cpu_
 CPU implementation that actually uses the host's cores ("the fp32 restatement
 executed with torch-CPU GEMMs"); tests/test_oracle_torch_cpu.py pins it to the numpy oracle.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -47,8 +49,9 @@ def _segment_sum(data, ids, n):
 
 
 def _gnn(params, gnn_name, nodes, edges, *, num_steps, embed_nodes, embed_edges, node_output=(),
-         live_nodes=None, chunk=1 << 17):
-  """edges: name -> dict(features, senders, receivers (LongTensors), senders_set, receivers_set)."""
+         live_nodes=None, chunk=1 << 17, taps=None):
+  """edges: name -> dict(features, senders, receivers (LongTensors), senders_set, receivers_set).
+  `taps` (dict or None) receives the last step's received aggregates as "agg:<edge set>"."""
   net = _Net(params, gnn_name)
   if embed_edges:
     for k, e in edges.items():
@@ -73,6 +76,10 @@ def _gnn(params, gnn_name, nodes, edges, *, num_steps, embed_nodes, embed_edges,
         continue
       received = [_segment_sum(new_edges[ek], e["receivers"], h.shape[0])
                   for ek, e in sorted(edges.items()) if e["receivers_set"] == k]
+      if taps is not None and last:
+        for (ek, e), r in zip([(ek, e) for ek, e in sorted(edges.items()) if e["receivers_set"] == k],
+                              received):
+          taps[f"agg:{ek}"] = r
       new_nodes[k] = net.apply(f"processor_nodes_{step}_{k}", h, *received)
     for k in list(nodes):
       if k in new_nodes:
@@ -87,8 +94,27 @@ def _gnn(params, gnn_name, nodes, edges, *, num_steps, embed_nodes, embed_edges,
   return nodes
 
 
-def forward(params, graphs, x_grid, steps):
-  """x_grid [N_grid, B, C_in] (numpy) -> [N_grid, B, C_out] (numpy float32)."""
+def set_threads(n=None):
+  """Threads for the CPU kernels: the host's PHYSICAL cores by default (SMT siblings only add
+  contention to fp32 GEMMs).  Returns the count in effect."""
+  if n is None:
+    n = os.cpu_count() or 1
+    try:
+      import psutil
+      n = psutil.cpu_count(logical=False) or n
+    except Exception:                                            # pragma: no cover
+      pass
+  torch.set_num_threads(max(1, int(n)))
+  return torch.get_num_threads()
+
+
+def forward(params, graphs, x_grid, steps, taps=None):
+  """x_grid [N_grid, B, C_in] (numpy) -> [N_grid, B, C_out] (numpy float32).
+
+  `taps` (a dict) additionally receives the stage boundaries of graphcast.py:311-319 as numpy
+  arrays: "enc_agg_mesh" (the grid2mesh segment-sum the encoder's mesh-node update consumes,
+  typed_graph_net.py:532-538), "latent_mesh" / "latent_grid" (after _run_grid2mesh_gnn),
+  "updated_mesh" (after _run_mesh_gnn)."""
   x = _t(x_grid)
   b = x.shape[1]
   batch = lambda a: _t(a)[:, None, :].expand(-1, b, -1)
@@ -101,7 +127,11 @@ def forward(params, graphs, x_grid, steps):
                {"grid_nodes": torch.cat([x, batch(graphs["grid_node_feat"])], -1),
                 "mesh_nodes": torch.cat([torch.zeros((n_mesh,) + tuple(x.shape[1:])), batch(graphs["mesh_node_feat"])], -1)},
                {"grid2mesh": edge(graphs["g2m"], "grid_nodes", "mesh_nodes")},
-               num_steps=1, embed_nodes=True, embed_edges=True)
+               num_steps=1, embed_nodes=True, embed_edges=True, taps=taps)
+    if taps is not None:
+      taps["enc_agg_mesh"] = taps.pop("agg:grid2mesh").numpy()
+      taps["latent_mesh"] = enc["mesh_nodes"].numpy()
+      taps["latent_grid"] = enc["grid_nodes"].numpy()
     proc = _gnn(params, "mesh_gnn", {"mesh_nodes": enc["mesh_nodes"]},
                 {"mesh": edge(graphs["mesh"], "mesh_nodes", "mesh_nodes")},
                 num_steps=steps, embed_nodes=False, embed_edges=True)
@@ -109,4 +139,6 @@ def forward(params, graphs, x_grid, steps):
                {"mesh2grid": edge(graphs["m2g"], "mesh_nodes", "grid_nodes")},
                num_steps=1, embed_nodes=False, embed_edges=True, node_output=("grid_nodes",),
                live_nodes=("grid_nodes",))
+    if taps is not None:
+      taps["updated_mesh"] = proc["mesh_nodes"].numpy()
   return dec["grid_nodes"].numpy()

@@ -522,3 +522,20 @@ def test_xarray_tree_map_structure_reference_cases():
     xarray_tree.map_structure("nope", ds)
   with pytest.raises(ValueError):
     xarray_tree.map_structure(lambda x: x)
+
+
+def test_split_rng_never_reuses_a_key():
+  """an rng this module cannot split must not be handed out unchanged chunk after
+  chunk (correlated noise across lead times): known key types split, unknown ones raise unless
+  the caller supplies the split."""
+  from graphcast_amd import rollout as ro
+  assert ro.split_rng(None) == (None, None)
+  for key in (7, np.uint32(7), np.random.SeedSequence(7), np.array([0, 7], dtype=np.uint32)):
+    carry, this = ro.split_rng(key)
+    assert isinstance(carry, np.random.SeedSequence) and isinstance(this, np.random.SeedSequence)
+    assert carry.generate_state(2).tolist() != this.generate_state(2).tolist()
+  g1, g2 = ro.split_rng(np.random.default_rng(3))
+  assert isinstance(g1, np.random.Generator) and g1.random() != g2.random()
+  with pytest.raises(TypeError, match="cannot split an rng"):
+    ro.split_rng("an opaque key")
+  assert ro.split_rng("k", split_fn=lambda k: (k + "a", k + "b")) == ("ka", "kb")

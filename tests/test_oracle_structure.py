@@ -162,3 +162,63 @@ def test_local_coordinate_helpers_match_reference_functions(golden_dir):
   np.testing.assert_allclose(mu.rotate_with_matrices(m, p), np.tile([1.0, 0.0, 0.0], (9, 1)), atol=1e-6)
   with pytest.raises(ValueError):
     mu.get_rotation_matrices_to_local_coordinates(z["phi"], z["theta"], rotate_latitude=False, rotate_longitude=False)
+
+
+def test_mesh2grid_product_equals_restated_oracle_hash_1deg(golden_dir):
+  """The product's mesh2grid indices at 1 deg / M5 vs the fingerprint of the oracle's
+  (tests/golden/make_m2g_hashes.py): two independent restatements of trimesh's rule agree,
+  tie points included (63 grid points lie exactly on a mesh edge at this size)."""
+  import hashlib
+  import json
+  import os
+  from graphcast_amd import grid_mesh_connectivity as gmc
+  from graphcast_amd import icosahedral_mesh as im
+  want = json.load(open(os.path.join(golden_dir, "m2g_restated_hashes.json")))["1deg_M5"]
+  lat = np.arange(-90, 90.5, 1.0).astype(np.float32)
+  lon = np.arange(0, 360, 1.0).astype(np.float32)
+  mesh = im.get_hierarchy_of_triangular_meshes_for_sphere(splits=5)[-1]
+  grid_idx, mesh_idx = gmc.in_mesh_triangle_indices(grid_latitude=lat, grid_longitude=lon, mesh=mesh)
+  h16 = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+  assert h16(np.asarray(grid_idx, np.int64)) == want["m2g_grid_idx"]["sha256_16"]
+  assert h16(np.asarray(mesh_idx, np.int64)) == want["m2g_mesh_idx"]["sha256_16"]
+
+
+def test_mesh2grid_face_indices_can_be_injected():
+  """Escape hatch for hosts that have trimesh (reference grid_mesh_connectivity.py:114-119):
+  a precomputed face per grid point replaces the restated rule, in the product and the oracle."""
+  from graphcast_amd import graphcast as gc
+  from graphcast_amd import grid_mesh_connectivity as gmc
+  from graphcast_amd import icosahedral_mesh as im
+  from oracle import graphcast as ogc
+  res, mesh_size = 10.0, 2
+  lat = np.arange(-90, 90 + res / 2, res).astype(np.float32)     # (the Predictor casts to float32)
+  lon = np.arange(0, 360, res).astype(np.float32)
+  mesh = im.get_hierarchy_of_triangular_meshes_for_sphere(splits=mesh_size)[-1]
+  own = gmc._nearest_face_on_surface(gmc._grid_lat_lon_to_coordinates(lat, lon).reshape([-1, 3]), mesh)
+  # same faces injected -> same graph; a different (valid) choice shows up in the edges
+  g0, m0 = gmc.in_mesh_triangle_indices(grid_latitude=lat, grid_longitude=lon, mesh=mesh)
+  g1, m1 = gmc.in_mesh_triangle_indices(grid_latitude=lat, grid_longitude=lon, mesh=mesh,
+                                        query_face_indices=own)
+  np.testing.assert_array_equal(m0, m1)
+  np.testing.assert_array_equal(g0, g1)
+  other = own.copy()
+  other[5] = (own[5] + 1) % len(mesh.faces)
+  _, m2 = gmc.in_mesh_triangle_indices(grid_latitude=lat, grid_longitude=lon, mesh=mesh,
+                                       query_face_indices=other)
+  np.testing.assert_array_equal(m2[15:18], mesh.faces[other[5]])
+  np.testing.assert_array_equal(np.delete(m2, [15, 16, 17]), np.delete(m0, [15, 16, 17]))
+  with pytest.raises(ValueError):
+    gmc.in_mesh_triangle_indices(grid_latitude=lat, grid_longitude=lon, mesh=mesh,
+                                 query_face_indices=own[:-1])
+  with pytest.raises(ValueError):
+    gmc.in_mesh_triangle_indices(grid_latitude=lat, grid_longitude=lon, mesh=mesh,
+                                 query_face_indices=np.full_like(own, len(mesh.faces)))
+  # the Predictor and the oracle take the same array
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=1,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  model = gc.GraphCast(cfg, gc.TASK_13, mesh2grid_face_indices=other).init_from_coordinates(lat, lon)
+  want = ogc.build_graphs(lat, lon, mesh_size, m2g_face_indices=other)
+  got = model.graph_arrays()
+  np.testing.assert_array_equal(got["m2g"]["senders"], want["m2g"]["senders"])
+  np.testing.assert_array_equal(got["m2g"]["receivers"], want["m2g"]["receivers"])
+  np.testing.assert_allclose(got["m2g"]["feat"], want["m2g"]["feat"], atol=1e-12)

@@ -18,7 +18,7 @@ def lib():
 @pytest.mark.parametrize("k,n,np_cols,chained", [(512, 512, 512, False), (474, 512, 512, False),
                                                  (512, 227, 256, True), (4, 512, 512, False),
                                                  (1024, 512, 512, False), (512, 512, 512, True)])
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16gemm"])
 def test_host_pack_weight_equals_numpy_packer(lib, prec, k, n, np_cols, chained):
   rng = np.random.default_rng(k + n)
   w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
@@ -152,7 +152,7 @@ def test_property_pack_edges_native_equals_numpy(n_recv, n_edges, seed, uniform)
 
 
 @settings(max_examples=25, deadline=None)
-@given(st.integers(1, 70), st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.sampled_from(["f32", "f16x3", "bf16"]),
+@given(st.integers(1, 70), st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.sampled_from(["f32", "f16x3", "bf16gemm"]),
        st.booleans(), st.floats(1e-4, 30.0))
 def test_property_pack_weight_native_equals_numpy(k, n, seed, prec, chained, magnitude):
   rng = np.random.default_rng(seed)

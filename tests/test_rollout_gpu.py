@@ -135,16 +135,17 @@ def test_device_rollout_matches_dataset_rollout(setup):
   np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)
 
 
-def test_bfloat16_cast_tier(setup):
-  """casting.Bfloat16Cast around GraphCast (the reference's demo stack, utils/casting.py:31-65):
-  checked against the oracle with the same GEMM-operand rounding; and the distance to the fp32
-  result is reported (the tier is outside the 1e-4 budget by design)."""
+def test_bf16_gemm_tier(setup):
+  """casting.Bf16GemmTier around GraphCast (bfloat16 GEMM operands, fp32 elsewhere -- NOT the
+  numerics of the reference's Bfloat16Cast, utils/casting.py:45-65): checked against the oracle
+  with the same GEMM-operand rounding; the distance to the fp32-grade result is reported (the tier
+  is outside the 1e-4 budget by design).  The reference's wrapper name refuses to run."""
   from graphcast_amd import casting
   from oracle import gnn as ognn
   model, oracle = setup
   inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, seed=21)
   full = model(inputs, template, forcings)
-  got = casting.Bfloat16Cast(model)(inputs, template, forcings)
+  got = casting.Bf16GemmTier(model)(inputs, template, forcings)
   assert model._precision is None                      # restored
   with ognn.gemm_operands("bf16"):
     want = oracle(casting.to_bfloat16_values(inputs), template, casting.to_bfloat16_values(forcings))
@@ -153,11 +154,15 @@ def test_bfloat16_cast_tier(setup):
     w = casting.to_bfloat16_values(xarray.Dataset({k: want[k]}))[k].values
     worst = max(worst, _rel(got[k].values, w))
     dist = max(dist, _rel(got[k].values, full[k].values))
-  print(f"bf16 tier: worst per-variable rel diff vs bf16-operand oracle {worst:.2e}; vs the fp32-grade path {dist:.2e}")
+  print(f"bf16gemm tier: worst per-variable rel diff vs bf16-operand oracle {worst:.2e}; vs the fp32-grade path {dist:.2e}")
   # two bf16 pipelines differing in fp32 summation order decorrelate to bf16 resolution within a
   # few layers, so both comparisons are at that resolution
   assert worst < 2e-2
   assert 1e-4 < dist < 5e-2
   # disabled wrapper = the wrapped predictor
+  same = casting.Bf16GemmTier(model, enabled=False)(inputs, template, forcings)
+  np.testing.assert_array_equal(same["temperature"].values, full["temperature"].values)
+  with pytest.raises(NotImplementedError):
+    casting.Bfloat16Cast(model)
   same = casting.Bfloat16Cast(model, enabled=False)(inputs, template, forcings)
   np.testing.assert_array_equal(same["temperature"].values, full["temperature"].values)

@@ -20,7 +20,7 @@ def rel_rmse(got, want):
   return float(np.linalg.norm(np.asarray(got, np.float64) - want) / np.linalg.norm(want))
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f16x3co", "f32", "bf16"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3co", "f32", "bf16gemm"])
 def small(request):
   # "f16x3co": f16x3 arithmetic with the MLP_LN launches in the column-owner formulation
   colown = request.param == "f16x3co"
@@ -53,7 +53,7 @@ def test_step_matches_oracle(small, batch):
   rng = np.random.default_rng(batch)
   x = rng.standard_normal((small["graphs"]["n_grid"], batch, small["c_in"])).astype(np.float32)
   from oracle import gnn as ognn
-  with ognn.gemm_operands("bf16" if small["precision"] == "bf16" else None):   # same operand rounding
+  with ognn.gemm_operands("bf16" if small["precision"] == "bf16gemm" else None):   # same operand rounding
     want = ogc.forward(small["params"], small["graphs"], x, steps=small["steps"], dtype=np.float64)
   y = small["model"].forward_grid_node_features(torch.from_numpy(x).to("cuda:0"))
   torch.cuda.synchronize()
@@ -65,11 +65,11 @@ def test_step_matches_oracle(small, batch):
   # bf16 tier: two bf16 pipelines that differ only in fp32 summation order decorrelate to bf16
   # resolution within a few layers (every re-rounding turns a difference d into sqrt(d * ulp)),
   # so the whole step can only be pinned at that resolution
-  tol = 1.5e-2 if small["precision"] == "bf16" else REL_RMSE_TOL
+  tol = 1.5e-2 if small["precision"] == "bf16gemm" else REL_RMSE_TOL
   assert err <= tol
   for b in range(batch):                        # per batch element too
     assert rel_rmse(got[:, b], want[:, b]) <= tol
-  if small["precision"] == "bf16":              # the tier is NOT fp32-grade: report how far it is
+  if small["precision"] == "bf16gemm":              # the tier is NOT fp32-grade: report how far it is
     truth = ogc.forward(small["params"], small["graphs"], x, steps=small["steps"], dtype=np.float64)
     print(f"bf16 tier vs float64 truth: rel-RMSE {rel_rmse(got, truth):.2e} (outside the 1e-4 fp32 budget by design)")
 
@@ -113,3 +113,38 @@ def test_step_matches_reference_golden_vectors(golden_dir, precision):
   err = rel_rmse(y.cpu().numpy(), z["out"])
   print(f"step rel-RMSE vs reference-executed golden vectors ({precision}): {err:.3e}")
   assert err <= REL_RMSE_TOL
+
+
+def test_step_with_injected_mesh2grid_faces_matches_oracle():
+  """SURVEY 8 a6 escape hatch: mesh2grid face indices supplied from outside (what a host with
+  trimesh would compute, reference grid_mesh_connectivity.py:114-119) drive the product's and the
+  oracle's decoder graph alike; the step on them matches the float64 oracle."""
+  from graphcast_amd import grid_mesh_connectivity as gmc
+  from graphcast_amd import icosahedral_mesh as im
+  res, mesh_size, steps = 6.0, 2, 2
+  lat = np.arange(-90, 90 + res / 2, res).astype(np.float32)
+  lon = np.arange(0, 360, res).astype(np.float32)
+  mesh = im.get_hierarchy_of_triangular_meshes_for_sphere(splits=mesh_size)[-1]
+  faces = gmc._nearest_face_on_surface(gmc._grid_lat_lon_to_coordinates(lat, lon).reshape([-1, 3]), mesh)
+  rng = np.random.default_rng(3)
+  pick = rng.choice(len(faces), size=40, replace=False)        # a different (valid) face for 40 points
+  faces = faces.copy()
+  faces[pick] = (faces[pick] + 1 + rng.integers(0, 5, size=40)) % len(mesh.faces)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=steps,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
+  params = oparams.init_params(c_in, c_out, 512, steps, seed=4, nontrivial=True)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params,
+                       mesh2grid_face_indices=faces).init_from_coordinates(lat, lon)
+  graphs = ogc.build_graphs(lat, lon, mesh_size, m2g_face_indices=faces)
+  np.testing.assert_array_equal(model.graph_arrays()["m2g"]["senders"], graphs["m2g"]["senders"])
+  x = rng.standard_normal((graphs["n_grid"], 1, c_in)).astype(np.float32)
+  want = ogc.forward(params, graphs, x, steps=steps, dtype=np.float64)
+  got = model.forward_grid_node_features(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+  base = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(lat, lon)
+  differs = base.forward_grid_node_features(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+  err = rel_rmse(got, want)
+  print(f"injected mesh2grid faces: rel-RMSE vs float64 oracle {err:.2e}; "
+        f"vs the restated-rule graph {rel_rmse(differs, want):.2e}")
+  assert err <= REL_RMSE_TOL
+  assert rel_rmse(differs, want) > 10 * REL_RMSE_TOL           # the injection really changed the graph
