@@ -223,7 +223,8 @@ class StepEngine:
 
   def _run(self, ops):
     arr = (nat.Op * len(ops))(*ops)
-    nat.check(self.lib.gc_run_program(arr, len(ops), self._stream_ptr()), "gc_run_program")
+    with torch.cuda.device(self.dev):
+      nat.check(self.lib.gc_run_program(arr, len(ops), self._stream_ptr()), "gc_run_program")
 
   def _mlp_ln(self, n_rows, mlp: _Mlp, **kw):
     return self._desc(nat.MODE_MLP_LN, n_rows, w2p=mlp.w2, b2=mlp.b2, n2=D,
@@ -427,7 +428,8 @@ class StepEngine:
 
   def forward(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
     arr, y = self.bind(x, y)
-    nat.check(self.lib.gc_run_program(arr, len(arr), self._stream_ptr()), "gc_run_program")
+    with torch.cuda.device(self.dev):       # launches go to the engine's device whatever is current
+      nat.check(self.lib.gc_run_program(arr, len(arr), self._stream_ptr()), "gc_run_program")
     return y
 
   __call__ = forward
@@ -450,7 +452,11 @@ class StepEngine:
     the current stream), then exchange the halo suffix of ``self.halo_table(table_name)`` with
     the other ranks (``table_name`` is None after the last segment).  18 exchange points per
     batch element: 1 encoder, 1 per processor step, 1 decoder."""
-    arr, y = self.bind(x, y)
+    bound, y = self.bind(x, y)
+    # a private copy of the program: the closures below stay valid when the engine is bound to
+    # other tensors before they have all run (interleaved partitioned steps, time_ops, ...)
+    arr = (nat.Op * len(bound))()
+    ctypes.memmove(arr, bound, ctypes.sizeof(bound))
     cuts = self._cuts[x.shape[1]]
     bounds = [0] + [c for c, _ in cuts] + [len(arr)]
     names = [n for _, n in cuts] + [None]
@@ -459,10 +465,10 @@ class StepEngine:
       lo, hi = bounds[k], bounds[k + 1]
       sub = ctypes.cast(ctypes.byref(arr, lo * ctypes.sizeof(nat.Op)), ctypes.POINTER(nat.Op))
 
-      def run(sub=sub, n=hi - lo):
-        nat.check(self.lib.gc_run_program(sub, n, self._stream_ptr()), "gc_run_program")
+      def run(sub=sub, n=hi - lo, keep=arr):        # (`keep`: the copy lives as long as the closure)
+        with torch.cuda.device(self.dev):
+          nat.check(self.lib.gc_run_program(sub, n, self._stream_ptr()), "gc_run_program")
       segs.append((run, names[k]))
-    self._bound = arr            # keeps the op array alive while the closures are in use
     return y, segs
 
   def halo_table(self, name: str) -> torch.Tensor:

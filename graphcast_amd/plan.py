@@ -73,12 +73,17 @@ class NativePlan:
     batch = x.shape[1]
     if y is None:
       y = torch.empty((self.n_grid, batch, self.c_out), dtype=torch.float32, device=self.dev)
+    elif (tuple(y.shape) != (self.n_grid, batch, self.c_out) or y.dtype != torch.float32
+          or not y.is_contiguous() or y.device != self.dev):
+      # (goes to the library as a raw pointer: a wrong y would be written out of bounds)
+      raise ValueError("y must be a contiguous float32 [N_grid, B, C_out] tensor on the plan's device")
     need = self.lib.gc_plan_workspace_bytes(self._plan, batch)
-    if self._ws is None or self._ws.numel() < need:
-      self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-    stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-    nat.check(self.lib.gc_step_forward(self._plan, x.data_ptr(), y.data_ptr(), batch, self._ws.data_ptr(),
-                                       self._ws.numel(), stream), "gc_step_forward")
+    with torch.cuda.device(self.dev):       # the launches go to THIS device's stream, whatever is current
+      if self._ws is None or self._ws.numel() < need:
+        self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+      stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+      nat.check(self.lib.gc_step_forward(self._plan, x.data_ptr(), y.data_ptr(), batch, self._ws.data_ptr(),
+                                         self._ws.numel(), stream), "gc_step_forward")
     return y
 
   __call__ = forward

@@ -68,11 +68,23 @@ def _channel_codes(ds: xarray.Dataset):
   return out
 
 
-def _stat(stats: Optional[xarray.Dataset], name: str, level_idx: int, default: float) -> float:
+def _stat(stats: Optional[xarray.Dataset], name: str, level, default: float) -> float:
+  """Statistic of `name` at pressure level LABEL `level` (None: a level-less variable).  Looked
+  up by label like xarray's alignment in normalization.py:29-48: published statistics carry 37
+  levels whatever the task uses, in whatever order the file has them."""
   if stats is None or name not in stats.keys():
     return default
-  v = np.asarray(stats[name].values, dtype=np.float64)
-  return float(v.reshape(-1)[max(level_idx, 0)] if v.ndim else v)
+  da = stats[name]
+  v = np.asarray(da.values, dtype=np.float64)
+  if not v.ndim:
+    return float(v)
+  if level is None:
+    raise ValueError(f"statistic {name!r} has a level axis but the variable has none")
+  labels = np.asarray(stats.coords["level"].values)
+  hit = np.nonzero(labels == level)[0]
+  if len(hit) != 1:
+    raise KeyError(f"level {level!r} not (uniquely) among the levels of statistic {name!r}")
+  return float(v.reshape(-1)[hit[0]])
 
 
 def build_tables(inputs, targets_template, forcings, stddev_by_level, mean_by_level,
@@ -88,6 +100,10 @@ def build_tables(inputs, targets_template, forcings, stddev_by_level, mean_by_le
   pos_f = {(n, l): i for i, (n, _, l) in enumerate(f_ch)}
   pos_t = {(n, l): i for i, (n, _, l) in enumerate(t_ch)}
   c_in, n_forc, c_out = len(in_ch) + len(f_ch), len(f_ch), len(t_ch)
+  level_labels = (np.asarray(inputs.coords["level"].values) if "level" in inputs.coords
+                  else np.asarray(targets_template.coords["level"].values) if "level" in targets_template.coords
+                  else None)
+  lab = lambda l: None if l < 0 else level_labels[l]      # level index of a channel -> its label
 
   src_x = np.full(c_in, -1, np.int32)
   src_y = np.full(c_in, -1, np.int32)
@@ -100,8 +116,8 @@ def build_tables(inputs, targets_template, forcings, stddev_by_level, mean_by_le
     elif t < n_in_frames - 1:                   # window shift: frame t <- frame t+1
       src_x[c], ax[c] = pos_in[(name, t + 1, l)], 1.0
     elif (name, l) in pos_t:                    # predicted: last frame + residual
-      std = _stat(stddev_by_level, name, l, 1.0)
-      dstd = _stat(diffs_stddev_by_level, name, l, 1.0)
+      std = _stat(stddev_by_level, name, lab(l), 1.0)
+      dstd = _stat(diffs_stddev_by_level, name, lab(l), 1.0)
       src_x[c], ax[c] = c, 1.0
       src_y[c], ay[c] = pos_t[(name, l)], dstd / std
     elif (name, l) in pos_f:                    # forced: value at the time just predicted
@@ -116,10 +132,10 @@ def build_tables(inputs, targets_template, forcings, stddev_by_level, mean_by_le
   p_ay = np.zeros(c_out, np.float32)
   p_b = np.zeros(c_out, np.float32)
   for k, (name, _, l) in enumerate(t_ch):
-    std, mean = _stat(stddev_by_level, name, l, 1.0), _stat(mean_by_level, name, l, 0.0)
+    std, mean = _stat(stddev_by_level, name, lab(l), 1.0), _stat(mean_by_level, name, lab(l), 0.0)
     if (name, n_in_frames - 1, l) in pos_in:    # residual target: y*dstd + (x_norm*std + mean)
       p_src_x[k] = pos_in[(name, n_in_frames - 1, l)]
-      p_ax[k], p_ay[k], p_b[k] = std, _stat(diffs_stddev_by_level, name, l, 1.0), mean
+      p_ax[k], p_ay[k], p_b[k] = std, _stat(diffs_stddev_by_level, name, lab(l), 1.0), mean
     else:                                       # direct target: y*std + mean
       p_ay[k], p_b[k] = std, mean
   return dict(c_in=c_in, c_out=c_out, n_forc=n_forc, src_x=src_x, src_y=src_y, src_f=src_f,

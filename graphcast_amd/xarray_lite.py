@@ -205,9 +205,34 @@ class Variable:
     bad = set(indexers) - set(self._dims)
     if bad:
       raise ValueError(f"Dimensions {bad} do not exist. Expected one or more of {self._dims}")
-    key = tuple(indexers.get(d, slice(None)) for d in self._dims)
-    dims = [d for d, k in zip(self._dims, key) if not isinstance(k, (int, np.integer))]
-    return Variable(dims, self._data[key])
+    # ORTHOGONAL (outer) indexing like xarray, one dimension at a time: handing the whole tuple to
+    # numpy would pair list indexers pointwise and, when an integer and a list are separated by a
+    # slice, move the advanced axes to the front while `dims` keeps the original order
+    data = self._data
+    drop = []
+    for axis, d in enumerate(self._dims):
+      k = indexers.get(d, slice(None))
+      if isinstance(k, (int, np.integer)):
+        drop.append(axis)
+        k = slice(int(k), int(k) + 1) if k != -1 else slice(-1, None)
+      if isinstance(k, slice):
+        if k != slice(None):
+          data = data[(slice(None),) * axis + (k,)]
+      else:
+        idx = np.asarray(k)
+        if idx.dtype == bool:
+          idx = np.nonzero(idx)[0]
+        if idx.ndim != 1:
+          raise IndexError(f"indexer for dimension {d!r} must be an int, a slice or 1-d")
+        if _is_torch(data):
+          import torch
+          data = torch.index_select(data, axis, torch.as_tensor(idx.astype(np.int64), device=data.device))
+        else:
+          data = np.take(data, idx, axis=axis)
+    dims = [d for axis, d in enumerate(self._dims) if axis not in drop]
+    if drop:
+      data = _reshape(data, tuple(n for axis, n in enumerate(data.shape) if axis not in drop))
+    return Variable(dims, data)
 
   def astype(self, dtype):
     return Variable(self._dims, _astype(self._data, dtype))
@@ -453,6 +478,25 @@ class DataArray:
   # by-name broadcasting arithmetic (normalization.py:29-48,113-132)
   def _binary(self, other, op):
     if isinstance(other, (DataArray, Variable)):
+      # xarray aligns on coordinate LABELS before the arithmetic (inner join): the reference's
+      # normalisation relies on it -- 37-level statistics applied to 13-level inputs
+      # (normalization.py:29-48).  Shared dims whose 1-d dimension coordinates differ are
+      # reindexed to the common labels, in this operand's order.
+      me = self
+      if isinstance(other, DataArray):
+        for d in self.dims:
+          if d in other.dims and d in self._coords and d in other._coords:
+            mine, theirs = np.asarray(self._coords[d].values), np.asarray(other._coords[d].values)
+            if mine.ndim == 1 and theirs.ndim == 1 and not (mine.shape == theirs.shape and (mine == theirs).all()):
+              where = {l: i for i, l in enumerate(theirs.tolist())}
+              keep = [i for i, l in enumerate(mine.tolist()) if l in where]
+              if not keep:
+                raise ValueError(f"no overlapping labels along {d!r}")
+              if len(keep) != len(mine):
+                me = me.isel({d: keep})
+              other = other.isel({d: [where[l] for l in np.asarray(me._coords[d].values).tolist()]})
+      if me is not self:
+        return me._binary(other, op)
       ov = other.variable
       dims = list(self.dims) + [d for d in ov.dims if d not in self.dims]
       sizes = dict(ov.sizes, **self.sizes)

@@ -24,6 +24,7 @@ from graphcast_amd import predictor_base
 from graphcast_amd import rollout
 from graphcast_amd import synthetic
 from graphcast_amd import xarray_lite as xarray
+xl = xarray
 
 LAT = np.arange(-90, 91, 30.0)
 LON = np.arange(0, 360, 45.0)
@@ -539,3 +540,53 @@ def test_split_rng_never_reuses_a_key():
   with pytest.raises(TypeError, match="cannot split an rng"):
     ro.split_rng("an opaque key")
   assert ro.split_rng("k", split_fn=lambda k: (k + "a", k + "b")) == ("ka", "kb")
+
+
+def test_isel_is_orthogonal_like_xarray():
+  """int + list indexers separated by a slice, and two list indexers, index each
+  dimension independently (xarray's outer indexing), never numpy's paired fancy indexing."""
+  a = np.arange(2 * 2 * 4).reshape(2, 2, 4)
+  v = xl.Variable(("time", "level", "lat"), a)
+  got = v.isel(time=0, lat=[1, 3])
+  assert got.dims == ("level", "lat")
+  np.testing.assert_array_equal(got.values, a[0][:, [1, 3]])          # [[1, 3], [5, 7]]
+  got = v.isel(level=[1, 0], lat=[0, 2, 3])
+  assert got.dims == ("time", "level", "lat") and got.shape == (2, 2, 3)
+  np.testing.assert_array_equal(got.values, a[:, [1, 0]][:, :, [0, 2, 3]])
+  np.testing.assert_array_equal(v.isel(time=-1, level=slice(0, 1)).values, a[-1, 0:1])
+  ds = xl.Dataset({"x": (("time", "level", "lat"), a)}, coords={"level": np.array([10, 20]), "lat": np.arange(4.0)})
+  sel = ds.sel(level=[20, 10], lat=[3.0, 0.0])
+  np.testing.assert_array_equal(sel["x"].values, a[:, [1, 0]][:, :, [3, 0]])
+  np.testing.assert_array_equal(sel.coords["level"].values, [20, 10])
+  torch = pytest.importorskip("torch")
+  tv = xl.Variable(("time", "level", "lat"), torch.from_numpy(a.copy()))
+  np.testing.assert_array_equal(tv.isel(time=0, lat=[1, 3]).values, a[0][:, [1, 3]])
+
+
+def test_arithmetic_aligns_on_level_labels_like_the_reference_normalisation():
+  """normalization.py:29-48 relies on xarray aligning `level` by LABEL -- the published
+  statistics have 37 levels (in file order), tasks use 13.  Same here, for the Dataset wrappers
+  and for DeviceRollout's channel tables."""
+  from graphcast_amd import normalization
+  from graphcast_amd import rollout_device
+  from graphcast_amd import variables as V
+  lv13 = np.asarray(V.PRESSURE_LEVELS_WEATHERBENCH_13)
+  lv37 = np.asarray(V.PRESSURE_LEVELS_ERA5_37)[::-1].copy()            # a DIFFERENT order on purpose
+  rng = np.random.default_rng(0)
+  x = xl.Dataset({"temperature": (("batch", "level", "lat"), rng.standard_normal((1, 13, 3)))},
+                 coords={"level": lv13})
+  mean = xl.Dataset({"temperature": (("level",), lv37 * 1.0)}, coords={"level": lv37})
+  std = xl.Dataset({"temperature": (("level",), lv37 * 0.5 + 1.0)}, coords={"level": lv37})
+  got = normalization.normalize(x, std, mean)["temperature"]
+  want = (x["temperature"].values - lv13[None, :, None]) / (lv13 * 0.5 + 1.0)[None, :, None]
+  np.testing.assert_allclose(got.values, want, rtol=1e-12)
+  np.testing.assert_array_equal(got.coords["level"].values, lv13)
+  # same-length statistics in another order are aligned too, not applied positionally
+  perm = rng.permutation(13)
+  mean13 = xl.Dataset({"temperature": (("level",), lv13[perm] * 1.0)}, coords={"level": lv13[perm]})
+  np.testing.assert_allclose((x["temperature"] - mean13["temperature"]).values,
+                             x["temperature"].values - lv13[None, :, None], rtol=1e-12)
+  assert rollout_device._stat(mean, "temperature", 500, 0.0) == 500.0
+  assert rollout_device._stat(mean, "absent", 500, 7.0) == 7.0
+  with pytest.raises(KeyError):
+    rollout_device._stat(mean, "temperature", 501, 0.0)
