@@ -16,7 +16,7 @@ MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
 OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_BF16_GEMM = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16gemm": PREC_BF16_GEMM}
-LAYOUT_CHUNKED, LAYOUT_COLOWN = 0, 1
+LAYOUT_CHUNKED, LAYOUT_COLOWN, LAYOUT_HALF = 0, 1, 2
 LATENT = 512
 TILE_ROWS = 64
 K_CHUNK = 32
@@ -41,6 +41,7 @@ class RowMlpDesc(ctypes.Structure):
       ("res", _fp), ("ldres", ctypes.c_int),
       ("out", _fp), ("ldo", ctypes.c_int),
       ("seg", _fp), ("tile_flags", _fp), ("agg", _fp), ("partial", _fp),
+      ("scratch", _fp),
   ]
 
 

@@ -973,6 +973,7 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
 }
 
 #include "rowmlp_colown.inc"
+#include "rowmlp_half.inc"
 
 // ---- GC_PREC_BF16_GEMM -----------------------------------------------------------------------
 // A reduced-precision tier: GEMM operands rounded to bfloat16 (round to nearest even), ONE
@@ -1381,6 +1382,25 @@ int launch_rowmlp_colown(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlpc_kernel");
 }
 
+bool g_h_attr_set[3] = {false, false, false};
+
+template <int MODE>
+int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
+  const size_t lds = kHLdsFloats * sizeof(float);
+  if (!g_h_attr_set[MODE]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16h_kernel<MODE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+      return GC_ELAUNCH;
+    }
+    g_h_attr_set[MODE] = true;
+  }
+  const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
+  hipLaunchKernelGGL(rowmlp16h_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
+  return check_launch("rowmlp16h_kernel");
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1406,8 +1426,13 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
   if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16_GEMM)
     return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
-  if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_COLOWN)
+  if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_COLOWN && d.layout != GC_LAYOUT_HALF)
     return fail(GC_EINVAL, "gc_rowmlp: unknown weight layout");
+  if (d.layout == GC_LAYOUT_HALF) {
+    if (d.prec != GC_PREC_F16X3) return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF is built for GC_PREC_F16X3 only");
+    if (d.mode == GC_MODE_MLP_LN && (!d.scratch || !aligned16(d.scratch)))
+      return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF + GC_MODE_MLP_LN needs a 16-byte aligned scratch");
+  }
   if (d.layout == GC_LAYOUT_COLOWN) {
     if (d.prec != GC_PREC_F16X3 || d.mode != GC_MODE_MLP_LN)
       return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_COLOWN is built for GC_PREC_F16X3 + GC_MODE_MLP_LN only");
@@ -1430,6 +1455,7 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   switch (d.mode) {
     case GC_MODE_LINEAR:
       if (!d.out || (d.ldo & 3) || !aligned16(d.out)) return fail(GC_EINVAL, "gc_rowmlp LINEAR: out must be 16B aligned, ldo % 4 == 0");
+      if (d.layout == GC_LAYOUT_HALF) return launch_rowmlp_half<GC_MODE_LINEAR>(d, s);
       return launch_rowmlp<GC_MODE_LINEAR>(d, s);
     case GC_MODE_MLP_LN:
       if (!d.w2p || !d.b2 || d.n2 != kD) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: needs w2p, b2, n2 == 512");
@@ -1443,9 +1469,11 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
         return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg)");
       }
       if (d.layout == GC_LAYOUT_COLOWN) return launch_rowmlp_colown(d, s);
+      if (d.layout == GC_LAYOUT_HALF) return launch_rowmlp_half<GC_MODE_MLP_LN>(d, s);
       return launch_rowmlp<GC_MODE_MLP_LN>(d, s);
     case GC_MODE_MLP_OUT:
       if (!d.w2p || !d.b2 || d.n2 <= 0 || d.n2 > 240 || !d.out) return fail(GC_EINVAL, "gc_rowmlp MLP_OUT: needs w2p, b2, out, 0 < n2 <= 240");
+      if (d.layout == GC_LAYOUT_HALF) return launch_rowmlp_half<GC_MODE_MLP_OUT>(d, s);
       return launch_rowmlp<GC_MODE_MLP_OUT>(d, s);
     default:
       return fail(GC_EINVAL, "gc_rowmlp: unknown mode");

@@ -36,6 +36,7 @@ D = packing.LATENT
 # Bfloat16Cast, see casting.py).  Overridable with
 # GCAST_PRECISION.
 DEFAULT_PRECISION = "f16x3"
+DEFAULT_HALF = "0"
 
 # stage tags reported by gc_time_program / used by bench.py
 TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, enc_node_grid=5,
@@ -127,7 +128,8 @@ class StepEngine:
   """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
 
   def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
-               device="cuda:0", precision: Optional[str] = None, colown: Optional[bool] = None):
+               device="cuda:0", precision: Optional[str] = None, colown: Optional[bool] = None,
+               half: Optional[bool] = None):
     self.dev = torch.device(device)
     self.lib = nat.lib()
     precision = precision or os.environ.get("GCAST_PRECISION", DEFAULT_PRECISION)
@@ -141,6 +143,13 @@ class StepEngine:
     if colown is None:
       colown = os.environ.get("GCAST_COLOWN", "0") == "1"
     self.colown = bool(colown) and self.prec == nat.PREC_F16X3
+    # f16x3 only: `half` / GCAST_HALF selects the half-N formulation for EVERY launch (csrc/
+    # rowmlp_half.inc: <= 256 VGPRs and 66 KiB of LDS per workgroup, two workgroups per CU, so one
+    # tile's non-GEMM phases run under the other's MFMAs).  Same packed weights as the chunked kernels.
+    if half is None:
+      half = os.environ.get("GCAST_HALF", DEFAULT_HALF) == "1"
+    self.half = bool(half) and self.prec == nat.PREC_F16X3 and not self.colown
+    self.scratch = None
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     # Spatially partitioned graphs (partition.plan): node tables that edges GATHER from carry a
     # halo suffix of remote sender rows behind the owned rows; kernels run over the owned prefix
@@ -183,7 +192,9 @@ class StepEngine:
     ds.a1, ds.k1, ds.lda1 = nat.ptr(a1), k1, (lda1 if lda1 is not None else (a1.shape[1] if a1 is not None else 0))
     co = (self.colown and mode == nat.MODE_MLP_LN and k0 <= D and k1 in (0, D)
           and (w1p is None or w1p.co is not None) and w2p is not None and w2p.co is not None)
-    ds.layout = nat.LAYOUT_COLOWN if co else nat.LAYOUT_CHUNKED
+    ds.layout = nat.LAYOUT_COLOWN if co else nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED
+    if self.half and mode == nat.MODE_MLP_LN:
+      ds.scratch = self._scratch_rows(n_rows).data_ptr()
     ds.w1p = nat.ptr(w1p.co if (co and w1p is not None) else w1p)
     ds.w1_scale = w1p.scale if w1p is not None else 1.0
     ds.d, ds.ldd = nat.ptr(d), (d.shape[1] if d is not None else 0)
@@ -200,6 +211,17 @@ class StepEngine:
       ds.seg, ds.tile_flags = nat.ptr(edges.rcv), nat.ptr(edges.flags)
       ds.agg, ds.partial = nat.ptr(agg), nat.ptr(edges.partial)
     return ds
+
+  def _scratch_rows(self, n_rows):
+    """GC_LAYOUT_HALF: [64 * ceil(n_rows / 64), 256] floats every MLP_LN launch may overwrite (its
+    rows park half of their layer-2 accumulators there between the two column passes).  ONE buffer
+    sized for the largest launch: launches of a step run one after another on one stream."""
+    need = -(-n_rows // packing.TILE) * packing.TILE
+    if self.scratch is None or self.scratch.shape[0] < need:
+      # (a smaller buffer handed to earlier descriptors stays alive in _keep and stays valid)
+      self.scratch = torch.empty((need, 256), dtype=torch.float32, device=self.dev)
+      self._keep.append(self.scratch)
+    return self.scratch
 
   def _op_mlp(self, tag, desc):
     op = nat.Op()

@@ -163,9 +163,17 @@ class DistExchanger:
   gloo on CPU).  Send rows are packed by one index_select, received rows land directly in the
   contiguous halo suffix of the table."""
 
-  def __init__(self, plan_: HaloPlan, n_owned: int, device, group=None):
+  def __init__(self, plan_: HaloPlan, n_owned: int, device, group=None, host_staged=None):
+    """`host_staged`: pack on the device, exchange through host buffers, unpack on the device --
+    for process groups that cannot move device memory (gloo; e.g. two ranks sharing ONE GPU in
+    tests).  Default: staged exactly when the table lives on a GPU and the group's backend is gloo."""
     import torch
+    import torch.distributed as dist
     self.n_owned, self.group = n_owned, group
+    if host_staged is None:
+      host_staged = (torch.device(device).type == "cuda" and dist.is_initialized()
+                     and dist.get_backend(group) == "gloo")
+    self.host_staged = bool(host_staged)
     self.send_counts = [int(len(i)) for i in plan_.send_local]
     self.recv_counts = [int(c) for c in plan_.recv_counts]
     idx = np.concatenate([np.asarray(i, dtype=np.int64) for i in plan_.send_local]) \
@@ -177,6 +185,13 @@ class DistExchanger:
     import torch.distributed as dist
     send = table.index_select(0, self.send_index) if self.send_index.numel() else table[:0]
     recv = table[self.n_owned:self.n_owned + sum(self.recv_counts)]
+    if self.host_staged:
+      send_h = send.contiguous().cpu()                 # (synchronises the launch stream: test path)
+      recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+      dist.all_to_all_single(recv_h, send_h, output_split_sizes=self.recv_counts,
+                             input_split_sizes=self.send_counts, group=self.group)
+      recv.copy_(recv_h)
+      return table
     dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=self.recv_counts,
                            input_split_sizes=self.send_counts, group=self.group)
     return table

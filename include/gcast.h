@@ -86,8 +86,14 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2 };
  *                      where lane l = 32 g + n holds part(scale * W[16 s + 8 g + j][128 wave + 32 cb + n]),
  *                      j = 0..7: one MFMA A fragment per 1 KiB, fetched with one coalesced
  *                      global_load_dwordx4 per lane.  Same (hi, lo) split, same scales as above.
- *                      Requires k0 <= 512 and k1 in {0, 512} (k1 > 0 only with k0 == 512). */
-enum gc_weight_layout { GC_LAYOUT_CHUNKED = 0, GC_LAYOUT_COLOWN = 1 };
+ *                      Requires k0 <= 512 and k1 in {0, 512} (k1 > 0 only with k0 == 512).
+ *   GC_LAYOUT_HALF     (GC_PREC_F16X3, all modes) the CHUNKED images unchanged, streamed as 32 KiB
+ *                      sub-chunks (the two 16-n-block halves of a chunk image); layer 2 runs as two
+ *                      passes over the output columns with pass 0's accumulators parked in
+ *                      `scratch`; <= 256 VGPRs and 66 KiB of LDS per workgroup, so that TWO
+ *                      workgroups share a CU and one's non-GEMM phases run under the other's MFMAs
+ *                      (csrc/rowmlp_half.inc).  MLP_LN launches need `scratch`. */
+enum gc_weight_layout { GC_LAYOUT_CHUNKED = 0, GC_LAYOUT_COLOWN = 1, GC_LAYOUT_HALF = 2 };
 
 /* What a fused row-MLP launch produces. */
 enum gc_rowmlp_mode {
@@ -150,6 +156,9 @@ typedef struct gc_rowmlp_desc {
                                           bit1: last run continues into the next tile */
   float* agg;              /* [n_receivers][512] rows owned entirely by one tile */
   float* partial;          /* [2*n_rows/64][512] straddling partial sums */
+  /* GC_LAYOUT_HALF + GC_MODE_MLP_LN: [64 * ceil(n_rows / 64)][256] floats the launch may overwrite
+   * (every row parks half of its layer-2 accumulators here between the two column passes) */
+  float* scratch;
 } gc_rowmlp_desc;
 
 int gc_rowmlp(const gc_rowmlp_desc* desc, void* stream);

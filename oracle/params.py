@@ -65,5 +65,60 @@ def init_params(c_in, c_out, latent, steps, seed=1, nontrivial=False):
   return params
 
 
+def conditioned_module_specs(c_grid, c_mesh, c_edge, c_out, latent):
+  """The GenCast encoder / decoder pair (weathernext1_gen/denoiser.py:303-363): the same
+  DeepTypedGraphNet modules as GraphCast's grid2mesh / mesh2grid GNNs, built with
+  ``use_norm_conditioning=True`` -- no LayerNorm parameters, one ``<stem>_norm_conditioning/linear``
+  per normalised MLP instead (deep_typed_graph_net.py:210-246, dense.py:360-393)."""
+  d = latent
+  specs = []
+  def add(gnn, stem, fan_in, out, cond=True):
+    specs.append((f"{gnn}/~_networks_builder/{stem}", [fan_in, d, out], cond))
+  g = "grid2mesh_gnn"
+  add(g, "encoder_edges_grid2mesh", c_edge, d)
+  add(g, "encoder_nodes_grid_nodes", c_grid, d)
+  add(g, "encoder_nodes_mesh_nodes", c_mesh, d)
+  add(g, "processor_edges_0_grid2mesh", 3 * d, d)
+  add(g, "processor_nodes_0_grid_nodes", d, d)
+  add(g, "processor_nodes_0_mesh_nodes", 2 * d, d)
+  g = "mesh2grid_gnn"
+  add(g, "encoder_edges_mesh2grid", c_edge, d)
+  add(g, "processor_edges_0_mesh2grid", 3 * d, d)
+  add(g, "processor_nodes_0_grid_nodes", 2 * d, d)
+  add(g, "processor_nodes_0_mesh_nodes", d, d)
+  add(g, "decoder_nodes_grid_nodes", d, c_out, cond=False)
+  return specs
+
+
+def init_conditioned_params(c_grid, c_mesh, c_edge, c_cond, c_out, latent, seed=1):
+  """Seeded float32 parameters of the norm-conditioned encoder / decoder.  The conditioning
+  layers are drawn at O(0.3) (the reference initialises them at ~1e-8, dense.py:381,385, which
+  would make the conditioning invisible to a test); biases are non-zero."""
+  rng = np.random.default_rng(seed)
+  params = {}
+  for stem, sizes, cond in conditioned_module_specs(c_grid, c_mesh, c_edge, c_out, latent):
+    for k in range(len(sizes) - 1):
+      fan_in, fan_out = sizes[k], sizes[k + 1]
+      w = stats.truncnorm.ppf(rng.random((fan_in, fan_out)), -2.0, 2.0) / np.sqrt(fan_in)
+      params[f"{stem}_mlp/~/linear_{k}"] = {
+          "w": w.astype(np.float32), "b": (0.1 * rng.standard_normal(fan_out)).astype(np.float32)}
+    if cond:
+      params[f"{stem}_norm_conditioning/linear"] = {
+          "w": (0.3 * rng.standard_normal((c_cond, 2 * sizes[-1]))).astype(np.float32),
+          "b": (0.3 * rng.standard_normal(2 * sizes[-1])).astype(np.float32)}
+  return params
+
+
+def digest(params):
+  """sha256 over the sorted float32 leaves (detects drift of a seed-regenerated tree)."""
+  import hashlib
+  h = hashlib.sha256()
+  for mod in sorted(params):
+    for leaf in sorted(params[mod]):
+      h.update(f"{mod}:{leaf}".encode())
+      h.update(np.ascontiguousarray(params[mod][leaf], dtype=np.float32).tobytes())
+  return h.hexdigest()
+
+
 def count(params):
   return sum(int(np.prod(a.shape)) for m in params.values() for a in m.values())

@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""A/B of single gc_rowmlp launches (shapes of the 0.25 deg step): the chunked kernels (one
+workgroup per CU) against the half-N kernels (GC_LAYOUT_HALF, two workgroups per CU), interleaved
+ABAB in one process so that both see the same clocks.  Extra builds of the half kernel can be
+compiled on the spot: HALF_BUILDS="tag:-DX=1,-DY=2;tag2:..."  GPU box only.
+
+    python scripts/half_probe.py [--out gpurun_out/half_probe.json] [--iters 20]
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphcast_amd import _native as nat      # noqa: E402
+from graphcast_amd import packing             # noqa: E402
+
+D = 512
+
+
+def build(tag, defines):
+  out = f"/tmp/libgcast_{tag}.so"
+  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm",
+         "-DGC_PIPE=2", *defines, "-I", os.path.join(ROOT, "include"), "-shared", "-fPIC",
+         os.path.join(ROOT, "graphcast_amd", "csrc", "gcast.hip"), "-o", out]
+  subprocess.run(cmd, check=True)
+  return load(out)
+
+
+def load(path):
+  lib = ctypes.CDLL(path)
+  lib.gc_rowmlp.argtypes = [ctypes.POINTER(nat.RowMlpDesc), ctypes.c_void_p]
+  lib.gc_rowmlp.restype = ctypes.c_int
+  lib.gc_last_error.restype = ctypes.c_char_p
+  return lib
+
+
+def time_launch(lib, d, iters):
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  for _ in range(2):
+    rc = lib.gc_rowmlp(ctypes.byref(d), stream)
+    assert rc == 0, lib.gc_last_error()
+  torch.cuda.synchronize()
+  t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0.record()
+  for _ in range(iters):
+    lib.gc_rowmlp(ctypes.byref(d), stream)
+  t1.record()
+  torch.cuda.synchronize()
+  return t0.elapsed_time(t1) / iters
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "half_probe.json"))
+  ap.add_argument("--iters", type=int, default=20)
+  ap.add_argument("--rounds", type=int, default=3)
+  args = ap.parse_args()
+  dev = torch.device("cuda:0")
+  rng = np.random.default_rng(0)
+  up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+  w = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+  sc = packing.choose_weight_scale(w)
+  w1 = up(packing.pack_weight_split(w, scale=sc).view(np.int16))
+  w2 = up(packing.pack_weight_split(w, chained=True, scale=sc).view(np.int16))
+  w1b = up(packing.pack_weight_split(np.concatenate([w, w]), scale=sc).view(np.int16))
+  wo = (rng.standard_normal((D, 227)) / np.sqrt(D)).astype(np.float32)
+  w2o = up(packing.pack_weight_split(wo, np_cols=256, chained=True, scale=sc).view(np.int16))
+  vec = up(0.1 * rng.standard_normal(D).astype(np.float32))
+  one = up(np.ones(D, np.float32))
+  n_mesh, n_g = 40962, 1038240
+  recv = np.repeat(np.arange(n_mesh), 8)
+  send = rng.integers(0, n_mesh, len(recv))
+  pk = packing.pack_edges(send, recv, n_mesh)
+  n_e = pk.n_rows
+  e = torch.randn((n_e, D), device=dev)
+  tab_s, tab_r = torch.randn((n_mesh, D), device=dev), torch.randn((n_mesh, D), device=dev)
+  agg = torch.empty((n_mesh, D), device=dev)
+  partial = torch.empty((2 * n_e // 64, D), device=dev)
+  snd, rcv, flags = up(pk.senders), up(pk.receivers), up(pk.tile_flags)
+  hg = torch.randn((n_g, D), device=dev)
+  og = torch.empty((n_g, D), device=dev)
+  yg = torch.empty((n_g, 227), device=dev)
+  # mesh2grid-like edges: 3 per grid node (uniform degree 3 -> 63 rows + 1 pad per tile), senders on the mesh
+  n_gd = n_g // 4                                   # a quarter of the grid: 0.78 M edges, 12 k tiles
+  recv3 = np.repeat(np.arange(n_gd), 3)
+  send3 = rng.integers(0, n_mesh, len(recv3))
+  pk3 = packing.pack_edges(send3, recv3, n_gd)
+  n_e3 = pk3.n_rows
+  d3 = torch.randn((n_e3, D), device=dev)
+  agg3 = torch.empty((n_gd, D), device=dev)
+  partial3 = torch.empty((2 * n_e3 // 64, D), device=dev)
+  snd3, rcv3, flags3 = up(pk3.senders), up(pk3.receivers), up(pk3.tile_flags)
+  scratch = torch.empty((max(n_g, n_e, n_e3) + 64, 256), device=dev)
+  prec = nat.PRECISIONS["f16x3"]
+  s1 = s2 = float(sc)
+
+  def desc(mode, n_rows, layout):
+    d = nat.RowMlpDesc()
+    d.mode, d.n_rows, d.prec, d.layout = mode, n_rows, prec, layout
+    d.w1_scale, d.w2_scale = s1, s2
+    d.scratch = scratch.data_ptr()
+    return d
+
+  def proc_edge(layout):
+    d = desc(nat.MODE_MLP_LN, n_e, layout)
+    d.a0, d.lda0, d.k0, d.w1p, d.b1 = e.data_ptr(), D, D, w1.data_ptr(), vec.data_ptr()
+    d.g0, d.idx0, d.g1, d.idx1 = tab_s.data_ptr(), snd.data_ptr(), tab_r.data_ptr(), rcv.data_ptr()
+    d.w2p, d.b2, d.n2 = w2.data_ptr(), vec.data_ptr(), D
+    d.ln_scale, d.ln_offset = one.data_ptr(), vec.data_ptr()
+    d.res, d.ldres, d.out, d.ldo = e.data_ptr(), D, og.data_ptr(), D       # (out != res: e stays put across iterations)
+    d.seg, d.tile_flags, d.agg, d.partial = rcv.data_ptr(), flags.data_ptr(), agg.data_ptr(), partial.data_ptr()
+    return d, n_e, 2.0 * n_e * 2 * D * D
+
+  def gemm_only_mlp(layout):
+    d = desc(nat.MODE_MLP_LN, n_e, layout)
+    d.a0, d.lda0, d.k0, d.w1p, d.b1 = e.data_ptr(), D, D, w1.data_ptr(), vec.data_ptr()
+    d.w2p, d.b2, d.n2 = w2.data_ptr(), vec.data_ptr(), D
+    d.ln_scale, d.ln_offset = one.data_ptr(), vec.data_ptr()
+    d.out, d.ldo = agg.data_ptr(), 0
+    return d, n_e, 2.0 * n_e * 2 * D * D
+
+  def dec_edge(layout):       # k0 = 0: addends only -> swish -> W2 -> LN -> segment-sum, nothing stored
+    d = desc(nat.MODE_MLP_LN, n_e3, layout)
+    d.w1_scale = 1.0
+    d.d, d.ldd = d3.data_ptr(), D
+    d.g0, d.idx0, d.g1, d.idx1 = tab_s.data_ptr(), snd3.data_ptr(), hg.data_ptr(), rcv3.data_ptr()
+    d.w2p, d.b2, d.n2 = w2.data_ptr(), vec.data_ptr(), D
+    d.ln_scale, d.ln_offset = one.data_ptr(), vec.data_ptr()
+    d.seg, d.tile_flags, d.agg, d.partial = rcv3.data_ptr(), flags3.data_ptr(), agg3.data_ptr(), partial3.data_ptr()
+    return d, n_e3, 2.0 * n_e3 * D * D
+
+  def linear_grid(layout):
+    d = desc(nat.MODE_LINEAR, n_g, layout)
+    d.a0, d.lda0, d.k0, d.w1p = hg.data_ptr(), D, D, w1.data_ptr()
+    d.out, d.ldo = og.data_ptr(), D
+    return d, n_g, 2.0 * n_g * D * D
+
+  def node_grid(layout):
+    d = desc(nat.MODE_MLP_LN, n_g, layout)
+    d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = hg.data_ptr(), D, D, og.data_ptr(), D, D
+    d.w1p, d.b1 = w1b.data_ptr(), vec.data_ptr()
+    d.w2p, d.b2, d.n2 = w2.data_ptr(), vec.data_ptr(), D
+    d.ln_scale, d.ln_offset = one.data_ptr(), vec.data_ptr()
+    d.res, d.ldres, d.out, d.ldo = hg.data_ptr(), D, og.data_ptr(), D
+    return d, n_g, 2.0 * n_g * 3 * D * D
+
+  def dec_out(layout):
+    d = desc(nat.MODE_MLP_OUT, n_g, layout)
+    d.a0, d.lda0, d.k0, d.w1p, d.b1 = hg.data_ptr(), D, D, w1.data_ptr(), vec.data_ptr()
+    d.w2p, d.b2, d.n2 = w2o.data_ptr(), vec.data_ptr(), 227
+    d.out, d.ldo = yg.data_ptr(), 227
+    return d, n_g, 2.0 * n_g * (D * D + D * 240)
+
+  shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, dec_edge=dec_edge, linear_grid=linear_grid,
+                node_grid=node_grid, dec_out=dec_out)
+  only = os.environ.get("PROBE_SHAPES")
+  if only:
+    shapes = {k: v for k, v in shapes.items() if k in only.split(",")}
+  libs = [("chunked", load(nat.library_path()), nat.LAYOUT_CHUNKED), ("half", load(nat.library_path()), nat.LAYOUT_HALF)]
+  for spec in filter(None, os.environ.get("HALF_BUILDS", "").split(";")):
+    tag, _, defs = spec.partition(":")
+    libs.append((tag, build(tag, [x for x in defs.split(",") if x]), nat.LAYOUT_HALF))
+  results = {}
+  for name, make in shapes.items():
+    row = {}
+    for r in range(args.rounds):                      # ABAB...: every build once per round
+      for tag, lib, layout in libs:
+        d, rows, flop = make(layout)
+        ms = time_launch(lib, d, args.iters)
+        row.setdefault(tag, []).append(ms)
+    out = {}
+    for tag, _, _ in libs:
+      ms = float(np.median(row[tag]))
+      d, rows, flop = make(nat.LAYOUT_CHUNKED)
+      out[tag] = {"ms": round(ms, 4), "ms_all": [round(v, 4) for v in row[tag]],
+                  "us_per_tile_per_cu": round(ms * 1e3 / (((rows + 63) // 64) / 256.0), 2),
+                  "algorithmic_tflops": round(flop / ms / 1e9, 1)}
+    results[name] = out
+    print(name, json.dumps(out), flush=True)
+  os.makedirs(os.path.dirname(args.out), exist_ok=True)
+  with open(args.out, "w") as f:
+    json.dump(results, f, indent=1)
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,103 @@
+"""Generates tests/golden/rollout40_1deg_rows.npz: the ORACLE's 40-step autoregressive rollout
+(BASELINE.json configs[2]) at 1 deg / 13 levels / M5 with 16 processor steps, through the
+reference's demo stack -- rollout.chunked_prediction (utils/rollout.py:326-364) around
+normalization.InputsAndResiduals (utils/normalization.py:148-160) around a Predictor whose step is
+the fp32 torch-CPU restatement (oracle/torch_cpu.py, pinned to the numpy oracle) -- sampled at 256
+fixed grid rows per lead time (the full trajectory is 0.87 GB).
+
+Why a fixture: 40 oracle steps are ~4 TFLOP each, 10+ minutes of host time; measured once live on
+the GPU box (profiles/r02_s1_rollout40_parity_1deg_live_oracle.json: rel-RMSE 3.3e-7 at step 1,
+6.6e-7 at step 40 over the FULL fields), afterwards the GPU test compares with these rows.
+Inputs, statistics and parameters are seeded (synthetic.make_example / make_stats,
+params.random_params): the test regenerates them and checks the stored digests.
+
+    python tests/golden/make_golden_rollout40.py          # ~10 minutes on 8 cores
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from graphcast_amd import graphcast as gc          # noqa: E402
+from graphcast_amd import model_utils              # noqa: E402
+from graphcast_amd import normalization            # noqa: E402
+from graphcast_amd import params as gparams        # noqa: E402
+from graphcast_amd import predictor_base           # noqa: E402
+from graphcast_amd import rollout                  # noqa: E402
+from graphcast_amd import synthetic                # noqa: E402
+from graphcast_amd import xarray_lite as xarray    # noqa: E402
+from oracle import graphcast as ogc                # noqa: E402
+from oracle import torch_cpu                       # noqa: E402
+
+RES, MESH, GNN_STEPS, N_STEPS, N_ROWS = 1.0, 5, 16, 40, 256
+SEEDS = dict(params=7, example=11, rows=3)
+LAT = np.arange(-90, 90 + RES / 2, RES)
+LON = np.arange(0, 360, RES)
+
+
+def setup():
+  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
+  params = gparams.random_params(c_in, c_out, 512, GNN_STEPS, seed=SEEDS["params"])
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, num_target_steps=N_STEPS,
+                                                      seed=SEEDS["example"])
+  stats = synthetic.make_stats(gc.TASK_13)
+  rows = np.sort(np.random.default_rng(SEEDS["rows"]).choice(len(LAT) * len(LON), N_ROWS, replace=False))
+  return params, inputs, template, forcings, stats, rows
+
+
+def digest(params, inputs, forcings):
+  h = hashlib.sha256()
+  for mod in sorted(params):
+    for leaf in sorted(params[mod]):
+      h.update(np.ascontiguousarray(params[mod][leaf], dtype=np.float32).tobytes())
+  for ds in (inputs, forcings):
+    for k in sorted(ds.keys()):
+      h.update(np.ascontiguousarray(ds[k].values, dtype=np.float32).tobytes())
+  return h.hexdigest()
+
+
+def stacked_rows(ds, template, s, rows):
+  """[len(rows), C_out] of lead time s, channels in the stacking order of graphcast.py:680-723."""
+  one = xarray.Dataset({k: ds[k].isel(time=slice(s, s + 1)) for k in sorted(template.keys())})
+  st = model_utils.lat_lon_to_leading_axes(model_utils.dataset_to_stacked(one))
+  data = np.asarray(st.data)
+  return data.reshape((-1,) + data.shape[2:])[rows, 0]
+
+
+class TorchOraclePredictor(predictor_base.Predictor):
+  def __init__(self, params, graphs):
+    self.params, self.graphs = params, graphs
+
+  def __call__(self, inputs, targets_template, forcings, **kw):
+    x = xarray.concat([model_utils.dataset_to_stacked(inputs),
+                       model_utils.dataset_to_stacked(forcings)], dim="channels")
+    x = np.asarray(model_utils.lat_lon_to_leading_axes(x).data, np.float32)
+    y = torch_cpu.forward(self.params, self.graphs, x.reshape((-1,) + x.shape[2:]), GNN_STEPS)
+    y = xarray.DataArray(y.reshape((len(LAT), len(LON)) + y.shape[1:]),
+                         dims=("lat", "lon", "batch", "channels"))
+    return model_utils.stacked_to_dataset(model_utils.restore_leading_axes(y).variable, targets_template)
+
+
+def main():
+  params, inputs, template, forcings, (mean, std, dstd), rows = setup()
+  graphs = ogc.build_graphs(LAT, LON, MESH)
+  torch_cpu.set_threads()
+  ref = normalization.InputsAndResiduals(TorchOraclePredictor(params, graphs), std, mean, dstd)
+  t0 = time.perf_counter()
+  want = rollout.chunked_prediction(lambda rng, **kw: ref(**kw), None, inputs, template, forcings)
+  dt = time.perf_counter() - t0
+  traj = np.stack([stacked_rows(want, template, s, rows) for s in range(N_STEPS)]).astype(np.float32)
+  np.savez_compressed(os.path.join(HERE, "rollout40_1deg_rows.npz"), rows=rows, traj=traj,
+                      inputs_sha256=np.array(digest(params, inputs, forcings)),
+                      config=np.array([RES, MESH, GNN_STEPS, N_STEPS]))
+  print(f"wrote rollout40_1deg_rows.npz: traj {traj.shape}, oracle {dt:.0f} s")
+
+
+if __name__ == "__main__":
+  main()

@@ -143,3 +143,43 @@ def test_norm_conditioned_nets_reproduce_reference_execution(golden_dir):
   with pytest.raises(KeyError):
     ognn.deep_typed_graph_net(params, "mesh2grid_gnn", dec_graph, num_steps=1, embed_nodes=False,
                               embed_edges=True, node_output=("grid_nodes",), dtype=np.float64)
+
+
+def load_conditioned512(golden_dir):
+  """(fixture, params regenerated from the stored seed -- digest-checked)."""
+  z = np.load(os.path.join(golden_dir, "gnn_conditioned512.npz"))
+  c_grid, c_mesh, c_edge, c_cond, c_out, latent, seed = (int(v) for v in z["config"])
+  params = oparams.init_conditioned_params(c_grid, c_mesh, c_edge, c_cond, c_out, latent, seed=seed)
+  assert oparams.digest(params) == str(z["params_sha256"]), "seed-regenerated parameters drifted"
+  return z, params
+
+
+def conditioned_oracle(z, params, dtype=np.float64):
+  b = z["cond"].shape[0]
+  rep = lambda e: np.repeat(np.asarray(e, dtype)[:, None, :], b, axis=1)
+  enc = ognn.deep_typed_graph_net(
+      params, "grid2mesh_gnn",
+      {"nodes": {"grid_nodes": z["grid_x"], "mesh_nodes": z["mesh_x"]},
+       "edges": {"grid2mesh": dict(features=rep(z["g2m_e"]), senders=z["g2m_senders"], receivers=z["g2m_receivers"],
+                                   senders_set="grid_nodes", receivers_set="mesh_nodes")}},
+      num_steps=1, embed_nodes=True, embed_edges=True, dtype=dtype, f32_aggregation=True,
+      norm_conditioning=z["cond"])
+  dec = ognn.deep_typed_graph_net(
+      params, "mesh2grid_gnn",
+      {"nodes": {"grid_nodes": enc["nodes"]["grid_nodes"], "mesh_nodes": enc["nodes"]["mesh_nodes"]},
+       "edges": {"mesh2grid": dict(features=rep(z["m2g_e"]), senders=z["m2g_senders"], receivers=z["m2g_receivers"],
+                                   senders_set="mesh_nodes", receivers_set="grid_nodes")}},
+      num_steps=1, embed_nodes=False, embed_edges=True, node_output=("grid_nodes",), dtype=dtype,
+      norm_conditioning=z["cond"])
+  return enc["nodes"]["grid_nodes"], enc["nodes"]["mesh_nodes"], dec["nodes"]["grid_nodes"]
+
+
+def test_oracle_reproduces_conditioned_latent512_reference_run(golden_dir):
+  """gnn_conditioned512.npz: the reference's norm-conditioned encoder / decoder executed at the
+  width the HIP kernels are built for; the oracle reproduces it (it is what the device path is
+  compared with on larger graphs, tests/test_conditioned_gpu.py)."""
+  z, params = load_conditioned512(golden_dir)
+  g, m, d = conditioned_oracle(z, params)
+  for got, want in ((g, z["enc_grid"]), (m, z["enc_mesh"]), (d, z["dec_grid"])):
+    assert got.shape == want.shape
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-9       # (f32_aggregation casts messages)

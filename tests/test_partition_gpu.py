@@ -63,3 +63,44 @@ def test_partitioned_step_against_oracle(setup):
       num_steps=setup["steps"], c_in=setup["c_in"], c_out=setup["c_out"])
   got = step(setup["x"]).cpu().numpy().astype(np.float64)
   assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-5
+
+
+def test_distributed_partitioned_step_two_ranks_share_one_gpu(setup, tmp_path):
+  """partition.DistributedPartitionedStep itself -- one process per rank, ONE all_to_all_single per
+  halo exchange -- executed with world_size 2: both ranks on this GPU, gloo group, host-staged
+  exchanger (RCCL refuses two ranks on one device).  Its assembled output equals the unpartitioned
+  step and the float64 oracle.  Reference design: utils/gather_scatter_ops.py:102-144,267-283."""
+  import os
+  import socket
+  import subprocess
+  import sys
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_partition_gpu_worker.py")
+  procs = []
+  for rank in range(2):
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path)], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+  outs = [p.communicate(timeout=600)[0] for p in procs]
+  for p, o in zip(procs, outs):
+    assert p.returncode == 0, o[-3000:]
+  n_grid = setup["x"].shape[0]
+  y = np.full((n_grid, 2, setup["c_out"]), np.nan, dtype=np.float32)
+  seen = np.zeros(n_grid, dtype=int)
+  for rank in range(2):
+    rows = np.load(tmp_path / f"rows_rank{rank}.npy")
+    y[rows] = np.load(tmp_path / f"y_rank{rank}.npy")
+    seen[rows] += 1
+  assert (seen == 1).all()                                         # every grid row owned exactly once
+  full = setup["y"].cpu().numpy()
+  rel = np.linalg.norm((y - full).astype(np.float64)) / np.linalg.norm(full.astype(np.float64))
+  graphs = ogc.build_graphs(setup["lat"], setup["lon"], setup["mesh_size"])
+  want = ogc.forward(setup["params"], graphs, setup["x"].cpu().numpy(), steps=setup["steps"])
+  rel_oracle = np.linalg.norm(y - want) / np.linalg.norm(want)
+  print(f"DistributedPartitionedStep, 2 ranks on one GPU (gloo, host-staged): rel diff vs unpartitioned "
+        f"{rel:.2e}, vs float64 oracle {rel_oracle:.2e}")
+  assert rel < 2e-6
+  assert rel_oracle < 2e-5

@@ -26,13 +26,16 @@ MAX_ABS_TOLS = {"f32": 2e-4, "f16x3": 2e-4, "bf16gemm": 2e-2}
 MAX_ABS_TOL = 2e-4
 _PREC = "f32"          # set per test by the autouse fixture below
 _CO = False            # "f16x3co": the MLP_LN launches run the column-owner formulation (GC_LAYOUT_COLOWN)
+_HALF = False          # "f16x3h": every launch runs the half-N formulation, two workgroups per CU (GC_LAYOUT_HALF)
+_SCRATCH = {}          # keeps the GC_LAYOUT_HALF scratch rows alive until the launch has run
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3co", "bf16gemm"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3co", "f16x3h", "bf16gemm"])
 def prec(request):
-  global _PREC, _CO
+  global _PREC, _CO, _HALF
   _CO = request.param == "f16x3co"
-  _PREC = "f16x3" if _CO else request.param
+  _HALF = request.param == "f16x3h"
+  _PREC = "f16x3" if (_CO or _HALF) else request.param
   if _CO and not any(k in request.node.name for k in ("mlp_ln", "edge_block")):
     pytest.skip("the column-owner layout only exists for MLP_LN launches")
   return _PREC
@@ -89,6 +92,12 @@ def new_desc(mode, n_rows):
   d = nat.RowMlpDesc()
   d.mode, d.n_rows, d.prec = mode, n_rows, nat.PRECISIONS[_PREC]
   d.layout = nat.LAYOUT_COLOWN if (_CO and mode == nat.MODE_MLP_LN) else nat.LAYOUT_CHUNKED
+  if _HALF:
+    d.layout = nat.LAYOUT_HALF
+    if mode == nat.MODE_MLP_LN:
+      rows = -(-n_rows // 64) * 64
+      _SCRATCH["t"] = torch.full((rows, 256), float("nan"), dtype=torch.float32, device="cuda:0")
+      d.scratch = _SCRATCH["t"].data_ptr()
   return d
 
 
