@@ -69,7 +69,7 @@ class ModelDesc(ctypes.Structure):
   _fields_ = [("n_grid", ctypes.c_int), ("n_mesh", ctypes.c_int), ("c_in", ctypes.c_int),
               ("c_out", ctypes.c_int), ("n_struct", ctypes.c_int), ("num_steps", ctypes.c_int),
               ("prec", ctypes.c_int), ("h_grid_node_feat", _fp), ("h_mesh_node_feat", _fp),
-              ("g2m", EdgeSet), ("mesh", EdgeSet), ("m2g", EdgeSet)]
+              ("g2m", EdgeSet), ("mesh", EdgeSet), ("m2g", EdgeSet), ("layout", ctypes.c_int)]
 
 
 class TensorDesc(ctypes.Structure):

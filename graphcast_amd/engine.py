@@ -36,7 +36,7 @@ D = packing.LATENT
 # Bfloat16Cast, see casting.py).  Overridable with
 # GCAST_PRECISION.
 DEFAULT_PRECISION = "f16x3"
-DEFAULT_HALF = "0"
+DEFAULT_HALF = "1"
 
 # stage tags reported by gc_time_program / used by bench.py
 TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, enc_node_grid=5,

@@ -39,11 +39,16 @@ class NativePlan:
   """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
 
   def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
-               device="cuda:0", precision: str = "f16x3"):
+               device="cuda:0", precision: str = "f16x3", half=None):
     self.lib = nat.lib()
     self.dev = torch.device(device)
     self.c_in, self.c_out = c_in, c_out
     self.n_grid = int(graphs["n_grid"])
+    if half is None:       # the same default as engine.StepEngine (bit-identical results, tests/test_plan_gpu.py)
+      import os
+      from graphcast_amd import engine
+      half = os.environ.get("GCAST_HALF", engine.DEFAULT_HALF) == "1"
+    self.half = bool(half) and precision == "f16x3"
     keep = []
 
     def edge_set(g):
@@ -55,7 +60,8 @@ class NativePlan:
     keep += [gnf, mnf]
     model = nat.ModelDesc(self.n_grid, int(graphs["n_mesh"]), c_in, c_out, gnf.shape[1], num_steps,
                           nat.PRECISIONS[precision], gnf.ctypes.data, mnf.ctypes.data,
-                          edge_set(graphs["g2m"]), edge_set(graphs["mesh"]), edge_set(graphs["m2g"]))
+                          edge_set(graphs["g2m"]), edge_set(graphs["mesh"]), edge_set(graphs["m2g"]),
+                          nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED)
     tensors, keep_t = tensor_descs(params)
     handle = ctypes.c_void_p()
     with torch.cuda.device(self.dev):

@@ -27,10 +27,13 @@ def case():
   return dict(graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16gemm"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3h", "f32", "bf16gemm"])
 @pytest.mark.parametrize("batch", [1, 2])
 def test_native_plan_equals_python_plan_bit_for_bit(case, precision, batch):
-  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"], precision=precision)
+  # "f16x3h": f16x3 arithmetic, every launch in the half-N formulation (GC_LAYOUT_HALF)
+  half = precision == "f16x3h"
+  precision = "f16x3" if half else precision
+  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"], precision=precision, half=half)
   eng = engine.StepEngine(case["graphs"], case["params"], colown=False, **kw)
   nat_plan = plan.NativePlan(case["graphs"], case["params"], **kw)
   rng = np.random.default_rng(batch)
