@@ -87,6 +87,8 @@ def op_flops(op, c_out_exec=240):
     f += 2.0 * m.n_rows * LATENT * LATENT
   elif m.mode == nat.MODE_MLP_OUT:
     f += 2.0 * m.n_rows * LATENT * c_out_exec
+  for k in range(m.n_chain):                      # Linear layers chained onto the launch (gc_chain_stage)
+    f += 2.0 * m.n_rows * LATENT * (c_out_exec if m.chain[k].kind == nat.CHAIN_NARROW else LATENT)
   return f
 
 

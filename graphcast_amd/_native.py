@@ -24,6 +24,16 @@ K_CHUNK = 32
 _fp = ctypes.c_void_p     # device pointers travel as integers
 
 
+class ChainStage(ctypes.Structure):
+  """struct gc_chain_stage."""
+  _fields_ = [("wp", _fp), ("b", _fp), ("out", _fp), ("ldo", ctypes.c_int), ("n", ctypes.c_int),
+              ("kind", ctypes.c_int), ("w_scale", ctypes.c_float)]
+
+
+MAX_CHAIN = 2
+CHAIN_LN, CHAIN_ROWS, CHAIN_SWISH, CHAIN_NARROW = 0, 1, 2, 3
+
+
 class RowMlpDesc(ctypes.Structure):
   """struct gc_rowmlp_desc (include/gcast.h) -- field order must match exactly."""
   _fields_ = [
@@ -42,6 +52,7 @@ class RowMlpDesc(ctypes.Structure):
       ("out", _fp), ("ldo", ctypes.c_int),
       ("seg", _fp), ("tile_flags", _fp), ("agg", _fp), ("partial", _fp),
       ("scratch", _fp),
+      ("n_chain", ctypes.c_int), ("chain", ChainStage * MAX_CHAIN),
   ]
 
 
@@ -55,6 +66,7 @@ class Op(ctypes.Structure):
       ("batch", ctypes.c_int), ("b", ctypes.c_int), ("c_in", ctypes.c_int),
       ("n_struct", ctypes.c_int), ("kp", ctypes.c_int),
       ("x", _fp), ("node_struct", _fp),
+      ("c0", ctypes.c_int),
   ]
 
 
@@ -91,7 +103,7 @@ class AdvanceDesc(ctypes.Structure):
 
 
 EXPORTS = ("gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_plan_destroy",
-           "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input",
+           "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_prep_grid_input", "gc_prep_grid_tail",
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
 
@@ -142,6 +154,8 @@ def lib():
     l.gc_zero_rows.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_void_p]
     l.gc_prep_grid_input.argtypes = [ctypes.c_int] * 4 + [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp,
                                                           ctypes.c_void_p]
+    l.gc_prep_grid_tail.argtypes = [ctypes.c_int] * 5 + [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp, ctypes.c_void_p]
+    l.gc_prep_grid_tail.restype = ctypes.c_int
     l.gc_advance_state.argtypes = [ctypes.POINTER(AdvanceDesc), ctypes.c_void_p]
     l.gc_advance_state.restype = ctypes.c_int
     l.gc_run_program.argtypes = [ctypes.POINTER(Op), ctypes.c_int, ctypes.c_void_p]

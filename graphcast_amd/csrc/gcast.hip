@@ -1275,25 +1275,26 @@ __global__ void zero_rows_kernel(int n, const int* __restrict__ rows, float* __r
   *reinterpret_cast<f4*>(agg + (size_t)rows[e] * kD + threadIdx.x * 4) = f4{0.f, 0.f, 0.f, 0.f};
 }
 
-__global__ void prep_grid_input_kernel(int n_rows, int batch, int b, int c_in,
+__global__ void prep_grid_input_kernel(int n_rows, int batch, int b, int c_in, int c0,
                                        const float* __restrict__ x, int n_struct,
                                        const float* __restrict__ node_struct, int kp,
                                        float* __restrict__ xin) {
-  // one wave per row, lanes stride over the kp output columns
+  // one wave per row, lanes stride over the kp output columns = input columns c0 .. c0 + kp - 1
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const float* src = x + ((size_t)row * batch + b) * c_in;
   const float* st = node_struct + (size_t)row * n_struct;
   float* dst = xin + (size_t)row * kp;
-  for (int c = lane; c < kp; c += 64) {
+  for (int o = lane; o < kp; o += 64) {
+    const int c = c0 + o;
     float v = 0.f;
     if (c < c_in) {
       v = src[c];
     } else if (c < c_in + n_struct) {
       v = st[c - c_in];
     }
-    dst[c] = v;
+    dst[o] = v;
   }
 }
 
@@ -1433,6 +1434,25 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
     if (d.mode == GC_MODE_MLP_LN && (!d.scratch || !aligned16(d.scratch)))
       return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF + GC_MODE_MLP_LN needs a 16-byte aligned scratch");
   }
+  if (d.n_chain != 0) {
+    if (d.layout != GC_LAYOUT_HALF || d.mode != GC_MODE_MLP_LN || d.seg)
+      return fail(GC_EINVAL, "gc_rowmlp: a chain needs GC_LAYOUT_HALF + GC_MODE_MLP_LN without segment-sum");
+    if (d.n_chain < 0 || d.n_chain > GC_MAX_CHAIN) return fail(GC_EINVAL, "gc_rowmlp: n_chain out of range");
+    for (int k = 0; k < d.n_chain; ++k) {
+      const gc_chain_stage& c = d.chain[k];
+      if (!c.wp || !aligned16(c.wp) || !aligned16(c.b) || !pow2_or_unset(c.w_scale) || c.w_scale == 0.f)
+        return fail(GC_EINVAL, "gc_rowmlp: chain stage needs 16-byte aligned wp / b and a power-of-two w_scale");
+      if (c.kind == GC_CHAIN_ROWS) {
+        if (!c.out || !aligned16(c.out) || (c.ldo & 3)) return fail(GC_EINVAL, "gc_rowmlp: GC_CHAIN_ROWS needs a 16-byte aligned out, ldo % 4 == 0");
+      } else if (c.kind == GC_CHAIN_NARROW) {
+        if (!c.out || c.n <= 0 || c.n > 240) return fail(GC_EINVAL, "gc_rowmlp: GC_CHAIN_NARROW needs out and 0 < n <= 240");
+      } else if (c.kind == GC_CHAIN_SWISH) {
+        if (k + 1 == d.n_chain) return fail(GC_EINVAL, "gc_rowmlp: GC_CHAIN_SWISH must feed a following stage");
+      } else {
+        return fail(GC_EINVAL, "gc_rowmlp: unknown chain kind");
+      }
+    }
+  }
   if (d.layout == GC_LAYOUT_COLOWN) {
     if (d.prec != GC_PREC_F16X3 || d.mode != GC_MODE_MLP_LN)
       return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_COLOWN is built for GC_PREC_F16X3 + GC_MODE_MLP_LN only");
@@ -1443,9 +1463,11 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (d.k0 == 0 && d.k1 != 0) return fail(GC_EINVAL, "gc_rowmlp: k1 without k0");
   if (d.k0 + d.k1 > 0 && (!d.a0 || !d.w1p)) return fail(GC_EINVAL, "gc_rowmlp: layer-1 GEMM needs a0 and w1p");
   if (d.k1 && !d.a1) return fail(GC_EINVAL, "gc_rowmlp: k1 > 0 needs a1");
-  if ((d.k0 && (d.lda0 & 3)) || (d.k1 && (d.lda1 & 3)) || (d.d && (d.ldd & 3)))
+  // (GC_LAYOUT_HALF reads its layer-1 rows with 4-byte aligned vector loads: any float row stride)
+  const bool rows_any = d.layout == GC_LAYOUT_HALF;
+  if ((!rows_any && ((d.k0 && (d.lda0 & 3)) || (d.k1 && (d.lda1 & 3)))) || (d.d && (d.ldd & 3)))
     return fail(GC_EINVAL, "gc_rowmlp: row strides must be multiples of 4 floats");
-  if (!aligned16(d.a0) || !aligned16(d.a1) || !aligned16(d.w1p) || !aligned16(d.d) || !aligned16(d.g0) ||
+  if ((!rows_any && (!aligned16(d.a0) || !aligned16(d.a1))) || !aligned16(d.w1p) || !aligned16(d.d) || !aligned16(d.g0) ||
       !aligned16(d.g1) || !aligned16(d.b1) || !aligned16(d.w2p) || !aligned16(d.b2) ||
       !aligned16(d.ln_scale) || !aligned16(d.ln_offset) || !aligned16(d.res) ||
       !aligned16(d.agg) || !aligned16(d.partial))
@@ -1461,12 +1483,13 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
       if (!d.w2p || !d.b2 || d.n2 != kD) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: needs w2p, b2, n2 == 512");
       if (d.ln_scale && !d.ln_offset) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: ln_scale without ln_offset");
       if (d.out && ((d.ldo & 3) || !aligned16(d.out))) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: out alignment");
-      if (d.res && (!d.out || (d.ldres & 3))) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: residual needs out, ldres % 4 == 0");
+      if (d.res && ((!d.out && d.n_chain == 0) || (d.ldres & 3)))
+        return fail(GC_EINVAL, "gc_rowmlp MLP_LN: residual needs out (or a chain), ldres % 4 == 0");
       if (d.seg) {
         if (d.n_rows % GC_TILE_ROWS) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: segment-sum needs n_rows % 64 == 0");
         if (!d.tile_flags || !d.agg || !d.partial) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: segment-sum needs tile_flags, agg, partial");
-      } else if (!d.out) {
-        return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg)");
+      } else if (!d.out && d.n_chain == 0) {
+        return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg, no chain)");
       }
       if (d.layout == GC_LAYOUT_COLOWN) return launch_rowmlp_colown(d, s);
       if (d.layout == GC_LAYOUT_HALF) return launch_rowmlp_half<GC_MODE_MLP_LN>(d, s);
@@ -1507,7 +1530,20 @@ int gc_prep_grid_input(int n_rows, int batch, int b, int c_in, const float* x, i
   const int rows_per_block = 4;
   hipLaunchKernelGGL(prep_grid_input_kernel, dim3((n_rows + rows_per_block - 1) / rows_per_block),
                      dim3(64 * rows_per_block), 0, static_cast<hipStream_t>(stream), n_rows, batch, b,
-                     c_in, x, n_struct, node_struct, kp, xin);
+                     c_in, 0, x, n_struct, node_struct, kp, xin);
+  return check_launch("prep_grid_input_kernel");
+}
+
+int gc_prep_grid_tail(int n_rows, int batch, int b, int c_in, int c0, const float* x, int n_struct,
+                      const float* node_struct, int kt, float* xt, void* stream) {
+  if (n_rows <= 0 || batch <= 0 || b < 0 || b >= batch || c_in <= 0 || n_struct < 0 || c0 < 0 || c0 > c_in ||
+      (c0 & 31) || kt < c_in - c0 + n_struct || (kt & 31))
+    return fail(GC_EINVAL, "gc_prep_grid_tail: bad sizes (c0, kt multiples of 32, kt >= c_in - c0 + n_struct)");
+  if (!x || !xt || (n_struct && !node_struct)) return fail(GC_EINVAL, "gc_prep_grid_tail: null pointer");
+  const int rows_per_block = 4;
+  hipLaunchKernelGGL(prep_grid_input_kernel, dim3((n_rows + rows_per_block - 1) / rows_per_block),
+                     dim3(64 * rows_per_block), 0, static_cast<hipStream_t>(stream), n_rows, batch, b,
+                     c_in, c0, x, n_struct, node_struct, kt, xt);
   return check_launch("prep_grid_input_kernel");
 }
 
@@ -1536,6 +1572,9 @@ static int run_op(const gc_op& op, void* stream) {
     case GC_OP_ZERO:
       return gc_zero_rows(op.n, op.i0, op.dst, stream);
     case GC_OP_PREP:
+      if (op.c0 > 0)
+        return gc_prep_grid_tail(op.n, op.batch, op.b, op.c_in, op.c0, op.x, op.n_struct, op.node_struct, op.kp,
+                                 op.dst, stream);
       return gc_prep_grid_input(op.n, op.batch, op.b, op.c_in, op.x, op.n_struct, op.node_struct, op.kp,
                                 op.dst, stream);
     default:

@@ -94,6 +94,7 @@ class _Mlp:
       pack2 = lambda w, np_cols: _PW(up(packing.pack_weight(w, np_cols=np_cols)))
     self.k_in = w1.shape[0]
     self.n_out = w2.shape[1]
+    self._w1_raw, self._pack2, self._chained = w1, pack2, {}
     # W1 either whole, or split into named row blocks of 512 (concat order)
     if split is None:
       self.w1 = pack1(w1)
@@ -124,6 +125,19 @@ class _Edges:
     self.partial = torch.empty((2 * pk.n_rows // packing.TILE, D), dtype=torch.float32, device=dev)
 
 
+def _chained(mlp: _Mlp, block=None):
+  """First-layer matrix of `mlp` (or its 512-row block `block` of a split one) packed like a
+  layer-2 matrix (chained K order): what a GC_CHAIN stage needs, because its K operand is the
+  producing launch's rows as they sit in the accumulator registers (include/gcast.h)."""
+  if block not in mlp._chained:
+    w = mlp._w1_raw
+    if block is not None:
+      j = {"e": 0, "s": 1, "r": 2, "h": 0, "a": 1}[block]
+      w = w[j * D:(j + 1) * D]
+    mlp._chained[block] = mlp._pack2(w, D)
+  return mlp._chained[block]
+
+
 class StepEngine:
   """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
 
@@ -150,6 +164,9 @@ class StepEngine:
       half = os.environ.get("GCAST_HALF", DEFAULT_HALF) == "1"
     self.half = bool(half) and self.prec == nat.PREC_F16X3 and not self.colown
     self.scratch = None
+    # chained Linear layers + in-place grid input (only the half-N kernels have them); GCAST_FUSE=0
+    # keeps one launch per reference layer group for A/B runs
+    self.fuse = self.half and os.environ.get("GCAST_FUSE", "1") == "1"
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     # Spatially partitioned graphs (partition.plan): node tables that edges GATHER from carry a
     # halo suffix of remote sender rows behind the owned rows; kernels run over the owned prefix
@@ -185,7 +202,7 @@ class StepEngine:
   def _desc(self, mode, n_rows, *, a0=None, k0=0, lda0=None, a1=None, k1=0, lda1=None, w1p=None,
             d=None, g0=None, idx0=None, g1=None, idx1=None, b1=None, w2p=None, b2=None, n2=0,
             ln=None, res=None, out=None, ldo=None, out_ptr=None, edges: Optional[_Edges] = None,
-            agg=None):
+            agg=None, chain=()):
     ds = nat.RowMlpDesc()
     ds.mode, ds.n_rows, ds.prec = mode, n_rows, self.prec
     ds.a0, ds.k0, ds.lda0 = nat.ptr(a0), k0, (lda0 if lda0 is not None else (a0.shape[1] if a0 is not None else 0))
@@ -195,6 +212,17 @@ class StepEngine:
     ds.layout = nat.LAYOUT_COLOWN if co else nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED
     if self.half and mode == nat.MODE_MLP_LN:
       ds.scratch = self._scratch_rows(n_rows).data_ptr()
+    ds.n_chain = len(chain)
+    for k, st in enumerate(chain):
+      c = ds.chain[k]
+      c.wp, c.w_scale, c.kind = st["w"].data_ptr(), st["w"].scale, st["kind"]
+      c.b = nat.ptr(st.get("b"))
+      if st.get("out_ptr") is not None:
+        c.out = st["out_ptr"]
+      else:
+        c.out = nat.ptr(st.get("out"))
+      c.ldo = st.get("ldo", st["out"].shape[1] if st.get("out") is not None else 0)
+      c.n = st.get("n", 0)
     ds.w1p = nat.ptr(w1p.co if (co and w1p is not None) else w1p)
     ds.w1_scale = w1p.scale if w1p is not None else 1.0
     ds.d, ds.ldd = nat.ptr(d), (d.shape[1] if d is not None else 0)
@@ -351,6 +379,15 @@ class StepEngine:
     """Op list for all batch elements; x / y pointers are patched per call."""
     if batch in self._programs:
       return self._programs[batch]
+    build = self._program_fused if self.fuse else self._program_plain
+    ops, x_slots, y_slots, cuts = build(batch)
+    arr = (nat.Op * len(ops))(*ops)
+    self._programs[batch] = (arr, x_slots, y_slots)
+    self._cuts[batch] = cuts
+    return self._programs[batch]
+
+  def _program_plain(self, batch):
+    """One launch per reference layer group (every formulation / precision)."""
     ng, nm = self.n_grid, self.n_mesh
     ops, x_slots, y_slots = [], [], []
     cuts = []          # (index of the first op AFTER a halo exchange point, which table)
@@ -359,7 +396,7 @@ class StepEngine:
       op.kind, op.tag, op.n = nat.OP_PREP, TAGS["prep"], ng
       op.batch, op.b, op.c_in, op.n_struct, op.kp = batch, b, self.c_in, self.n_struct, self.kp
       op.node_struct, op.dst = nat.ptr(self.grid_struct), nat.ptr(self.xin)
-      x_slots.append(len(ops))
+      x_slots.append((len(ops), "prep"))
       ops.append(op)
       # ---- encoder (grid2mesh GNN) ----
       m = self.m_enc_grid
@@ -389,18 +426,7 @@ class StepEngine:
         ops.append(self._op_mlp("proc_pre", self._desc(
             nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=me.w1["r"], out=self.pre_r_mesh)))
         cuts.append((len(ops), "mesh"))
-        common = dict(g0=self.pre_s_mesh, idx0=self.e_mesh.snd, g1=self.pre_r_mesh,
-                      idx1=self.e_mesh.rcv, edges=self.e_mesh, agg=self.agg_mesh)
-        if i == 0:
-          desc = self._mlp_ln(self.e_mesh.n_rows, me, d=self.d_mesh0, res=self.e_mesh0,
-                              out=None if last else self.e_mesh_lat, **common)
-          if last:
-            desc.res, desc.ldres = None, 0
-        else:
-          desc = self._mlp_ln(self.e_mesh.n_rows, me, a0=self.e_mesh_lat, k0=D, w1p=me.w1["e"],
-                              b1=me.b1, res=None if last else self.e_mesh_lat,
-                              out=None if last else self.e_mesh_lat, **common)
-        ops.append(self._op_mlp("proc_edge", desc))
+        ops.append(self._op_mlp("proc_edge", self._proc_edge_desc(i)))
         ops += self._ops_after_segsum(self.e_mesh, self.agg_mesh)
         ops.append(self._op_mlp("proc_node", self._mlp_ln(
             nm, mn, a0=self.h_mesh, k0=D, a1=self.agg_mesh, k1=D, w1p=mn.w1, b1=mn.b1,
@@ -421,14 +447,106 @@ class StepEngine:
           ng, m, a0=self.h_grid2, k0=D, a1=self.agg_grid, k1=D, w1p=m.w1, b1=m.b1,
           res=self.h_grid2, out=self.h_grid)))
       m = self.m_out
-      y_slots.append(len(ops))
+      y_slots.append((len(ops), "out"))
       ops.append(self._op_mlp("dec_out", self._desc(
           nat.MODE_MLP_OUT, ng, a0=self.h_grid, k0=D, w1p=m.w1, b1=m.b1, w2p=m.w2, b2=m.b2,
           n2=self.c_out, out_ptr=0, ldo=batch * self.c_out)))
-    arr = (nat.Op * len(ops))(*ops)
-    self._programs[batch] = (arr, x_slots, y_slots)
-    self._cuts[batch] = cuts
-    return self._programs[batch]
+    return ops, x_slots, y_slots, cuts
+
+  def _proc_edge_desc(self, i):
+    me = self.m_proc_edge[i]
+    last = i == self.num_steps - 1
+    common = dict(g0=self.pre_s_mesh, idx0=self.e_mesh.snd, g1=self.pre_r_mesh,
+                  idx1=self.e_mesh.rcv, edges=self.e_mesh, agg=self.agg_mesh)
+    if i == 0:
+      desc = self._mlp_ln(self.e_mesh.n_rows, me, d=self.d_mesh0, res=self.e_mesh0,
+                          out=None if last else self.e_mesh_lat, **common)
+      if last:
+        desc.res, desc.ldres = None, 0
+      return desc
+    return self._mlp_ln(self.e_mesh.n_rows, me, a0=self.e_mesh_lat, k0=D, w1p=me.w1["e"],
+                        b1=me.b1, res=None if last else self.e_mesh_lat,
+                        out=None if last else self.e_mesh_lat, **common)
+
+  def _program_fused(self, batch):
+    """GC_LAYOUT_HALF: the Linear layers that the reference applies to rows a launch has just
+    produced are CHAINED onto that launch (gc_chain_stage: the rows are still in registers) --
+      grid embedder      -> (h.W_s)            the encoder edge update's sender product
+                                               (graphcast.py:561-598 + typed_graph_net.py:431-453)
+      encoder grid nodes -> (h'.W_r)           the decoder edge update's receiver product (:641-678)
+      encoder mesh nodes / processor node update i -> (h.W_s, h.W_r) of edge update i + 1
+                                               (the last one: the decoder's sender product)
+      decoder grid nodes -> swish(h.W1 + b1) -> .W2 + b2   the output MLP (deep_typed_graph_net.py:313-322)
+    -- 36 launches, their row re-reads and the [N_grid, 512] write + read of the decoder latents
+    disappear; the grid input is read in place (x[:, b, :448] as the first K chunks, a 32-column
+    tail [x[:, b, 448:] | struct | 0] built by gc_prep_grid_input) instead of being copied."""
+    ng, nm = self.n_grid, self.n_mesh
+    ops, x_slots, y_slots = [], [], []
+    cuts = []
+    R, S, N = nat.CHAIN_ROWS, nat.CHAIN_SWISH, nat.CHAIN_NARROW
+    rows = lambda mlp, blk, out: dict(w=_chained(mlp, blk), kind=R, out=out)
+    k_full = (self.c_in // packing.K_CHUNK) * packing.K_CHUNK          # x columns read in place
+    kt = self.kp - k_full                                              # tail: rest of x | struct | 0
+    for b in range(batch):
+      op = nat.Op()
+      op.kind, op.tag, op.n = nat.OP_PREP, TAGS["prep"], ng
+      op.batch, op.b, op.c_in, op.n_struct, op.kp = batch, b, self.c_in, self.n_struct, kt
+      op.c0 = k_full
+      op.node_struct, op.dst = nat.ptr(self.grid_struct), nat.ptr(self.xin)
+      x_slots.append((len(ops), "prep"))
+      ops.append(op)
+      # ---- encoder (grid2mesh GNN) ----
+      m = self.m_enc_grid
+      x_slots.append((len(ops), "a0", b))
+      ops.append(self._op_mlp("enc_embed_grid", self._mlp_ln(
+          ng, m, a0=self.xin, k0=k_full, lda0=batch * self.c_in, a1=self.xin, k1=kt, lda1=kt,
+          w1p=m.w1, b1=m.b1, out=self.h_grid, chain=[rows(self.m_g2m_edge, "s", self.pre_grid)])))
+      m = self.m_g2m_edge
+      cuts.append((len(ops), "g2m"))
+      ops.append(self._op_mlp("enc_edge", self._mlp_ln(
+          self.e_g2m.n_rows, m, d=self.d_g2m, g0=self.pre_grid, idx0=self.e_g2m.snd,
+          edges=self.e_g2m, agg=self.agg_mesh)))
+      ops += self._ops_after_segsum(self.e_g2m, self.agg_mesh)
+      m = self.m_g2m_mesh
+      first = self.m_proc_edge[0]
+      ops.append(self._op_mlp("enc_node_mesh", self._mlp_ln(
+          nm, m, a0=self.agg_mesh, k0=D, w1p=m.w1["a"], d=self.d_enc_mesh, res=self.h_mesh0,
+          out=self.h_mesh, chain=[rows(first, "s", self.pre_s_mesh), rows(first, "r", self.pre_r_mesh)])))
+      m = self.m_g2m_grid
+      ops.append(self._op_mlp("enc_node_grid", self._mlp_ln(
+          ng, m, a0=self.h_grid, k0=D, w1p=m.w1, b1=m.b1, res=self.h_grid, out=self.h_grid2,
+          chain=[rows(self.m_m2g_edge, "r", self.pre_grid)])))
+      # (h'.W_r overwrites pre_grid: the encoder edge update that gathered h.W_s from it has run)
+      # ---- processor (multi-mesh GNN) ----
+      for i in range(self.num_steps):
+        mn = self.m_proc_node[i]
+        last = i == self.num_steps - 1
+        cuts.append((len(ops), "mesh"))
+        ops.append(self._op_mlp("proc_edge", self._proc_edge_desc(i)))
+        ops += self._ops_after_segsum(self.e_mesh, self.agg_mesh)
+        if last:
+          chain = [rows(self.m_m2g_edge, "s", self.pre_s_mesh)]
+        else:
+          nxt = self.m_proc_edge[i + 1]
+          chain = [rows(nxt, "s", self.pre_s_mesh), rows(nxt, "r", self.pre_r_mesh)]
+        ops.append(self._op_mlp("proc_node", self._mlp_ln(
+            nm, mn, a0=self.h_mesh, k0=D, a1=self.agg_mesh, k1=D, w1p=mn.w1, b1=mn.b1,
+            res=self.h_mesh, out=self.h_mesh, chain=chain)))
+      # ---- decoder (mesh2grid GNN) ----
+      m = self.m_m2g_edge
+      cuts.append((len(ops), "m2g"))
+      ops.append(self._op_mlp("dec_edge", self._mlp_ln(
+          self.e_m2g.n_rows, m, d=self.d_m2g, g0=self.pre_s_mesh, idx0=self.e_m2g.snd,
+          g1=self.pre_grid, idx1=self.e_m2g.rcv, edges=self.e_m2g, agg=self.agg_grid)))
+      ops += self._ops_after_segsum(self.e_m2g, self.agg_grid)
+      m, mo = self.m_m2g_grid, self.m_out
+      y_slots.append((len(ops), "chain", 1))
+      ops.append(self._op_mlp("dec_node", self._mlp_ln(
+          ng, m, a0=self.h_grid2, k0=D, a1=self.agg_grid, k1=D, w1p=m.w1, b1=m.b1,
+          res=self.h_grid2, out=None,
+          chain=[dict(w=_chained(mo), kind=S, b=mo.b1),
+                 dict(w=mo.w2, kind=N, b=mo.b2, out_ptr=0, ldo=batch * self.c_out, n=self.c_out)])))
+    return ops, x_slots, y_slots, cuts
 
   def bind(self, x: torch.Tensor, y: Optional[torch.Tensor] = None):
     """Validates x/y and returns (program array, y) with the x/y pointers patched in."""
@@ -443,9 +561,17 @@ class StepEngine:
           or not y.is_contiguous() or y.device != self.dev):
       raise ValueError("y must be a contiguous float32 [N_grid, B, C_out] tensor on the engine's device")
     arr, x_slots, y_slots = self._program(batch)
-    for b in range(batch):
-      arr[x_slots[b]].x = x.data_ptr()
-      arr[y_slots[b]].mlp.out = y.data_ptr() + 4 * b * self.c_out
+    for slot in x_slots:
+      if slot[1] == "prep":
+        arr[slot[0]].x = x.data_ptr()
+      else:                                      # the embed launch reads x[:, b, :k_full] in place
+        arr[slot[0]].mlp.a0 = x.data_ptr() + 4 * slot[2] * self.c_in
+    for b, slot in enumerate(y_slots):
+      ptr = y.data_ptr() + 4 * b * self.c_out
+      if slot[1] == "out":
+        arr[slot[0]].mlp.out = ptr
+      else:
+        arr[slot[0]].mlp.chain[slot[2]].out = ptr
     return arr, y
 
   def forward(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:

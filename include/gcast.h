@@ -106,6 +106,27 @@ enum gc_rowmlp_mode {
   GC_MODE_MLP_OUT = 2
 };
 
+/* GC_LAYOUT_HALF + GC_MODE_MLP_LN: further Linear layers applied to the rows a launch has just
+ * produced (out = [res +] LN(...)), while they are still in registers -- the reference applies them
+ * as separate layers of the NEXT module: the next edge update's sender / receiver products
+ * (typed_graph_net.py:431-453 after the pre-gather split), the decoder's output MLP
+ * (deep_typed_graph_net.py:313-322).  Stages run in order; their weights are packed like a layer-2
+ * matrix (chained K order), NP = 512 (ROWS / SWISH) or 256 (NARROW).
+ *   GC_CHAIN_ROWS    out[r, 0:512] = rows[r] . W + b          (row stride ldo); rows unchanged
+ *   GC_CHAIN_SWISH   rows[r] <- swish(rows[r] . W + b)        nothing stored
+ *   GC_CHAIN_NARROW  out[r, 0:n]  = rows[r] . W + b, n <= 240 (row stride ldo)
+ * (GC_CHAIN_LN is the launch's own layer-2 epilogue; not a valid chain kind.) */
+enum gc_chain_kind { GC_CHAIN_LN = 0, GC_CHAIN_ROWS = 1, GC_CHAIN_SWISH = 2, GC_CHAIN_NARROW = 3 };
+typedef struct gc_chain_stage {
+  const void* wp;          /* packed weights (16 K steps of NP * 128 bytes) */
+  const float* b;          /* [NP] bias or NULL */
+  float* out; int ldo;     /* ROWS / NARROW */
+  int n;                   /* NARROW: real output width */
+  int kind;                /* enum gc_chain_kind */
+  float w_scale;           /* power of two the packed weights carry */
+} gc_chain_stage;
+#define GC_MAX_CHAIN 2
+
 /* One fused "rows -> MLP (-> LayerNorm) (-> residual) (-> segment-sum)" launch.
  *
  * Replaces, per reference call site:
@@ -159,6 +180,10 @@ typedef struct gc_rowmlp_desc {
   /* GC_LAYOUT_HALF + GC_MODE_MLP_LN: [64 * ceil(n_rows / 64)][256] floats the launch may overwrite
    * (every row parks half of its layer-2 accumulators here between the two column passes) */
   float* scratch;
+  /* GC_LAYOUT_HALF + GC_MODE_MLP_LN, no segment-sum: chained stages (see gc_chain_stage); with a
+   * chain `out` may be NULL (the rows are only consumed by the chain) */
+  int n_chain;
+  gc_chain_stage chain[GC_MAX_CHAIN];
 } gc_rowmlp_desc;
 
 int gc_rowmlp(const gc_rowmlp_desc* desc, void* stream);
@@ -179,6 +204,14 @@ int gc_zero_rows(int n, const int* rows, float* agg, void* stream);
 int gc_prep_grid_input(int n_rows, int batch, int b, int c_in, const float* x,
                        int n_struct, const float* node_struct, int kp, float* xin,
                        void* stream);
+
+/* The same for input columns c0 .. c0 + kt - 1 only (c0 a multiple of 32 <= c_in):
+ * xt[r, :] = [ x[r, b, c0:c_in] | node_struct[r, :] | 0-pad ] (row stride kt).  With it a
+ * GC_LAYOUT_HALF launch reads x[:, b, 0:c0] IN PLACE as its first K chunks (a0 = x + b * c_in,
+ * lda0 = batch * c_in, k0 = c0; any float alignment) and this 32-column tail as the last one
+ * (a1 = xt, k1 = kt) -- the [n_rows, kp] copy of gc_prep_grid_input is not made. */
+int gc_prep_grid_tail(int n_rows, int batch, int b, int c_in, int c0, const float* x,
+                      int n_struct, const float* node_struct, int kt, float* xt, void* stream);
 
 /* One autoregressive state advance, entirely on the device: builds the NORMALISED stacked
  * inputs of step s+1 from those of step s, the step's normalised output and the forcings,
@@ -226,6 +259,7 @@ typedef struct gc_op {
   /* GC_OP_PREP */
   int batch, b, c_in, n_struct, kp;
   const float* x; const float* node_struct;
+  int c0;                  /* > 0: gc_prep_grid_tail with kt = kp */
 } gc_op;
 
 int gc_run_program(const gc_op* h_ops, int n_ops, void* stream);

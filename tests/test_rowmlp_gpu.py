@@ -390,3 +390,135 @@ def test_prep_grid_input(dev):
   np.testing.assert_array_equal(got[:, :c_in], x[:, 1])
   np.testing.assert_array_equal(got[:, c_in:c_in + 3], st)
   assert (got[:, c_in + 3:] == 0).all()
+
+
+# ---- GC_LAYOUT_HALF only: chained stages and in-place (unaligned) layer-1 rows ------------------
+def _half_only():
+  if not _HALF:
+    pytest.skip("chained stages / unaligned rows exist in the half-N formulation only")
+
+
+def _ln(y, scale, offset):
+  mean = y.mean(axis=1, keepdims=True)
+  var = np.square(y - mean).mean(axis=1, keepdims=True)
+  return (y - mean) / np.sqrt(var + 1e-5) * scale + offset
+
+
+def _chain_stage(d, k, w_img, kind, b=None, out=None, ldo=0, n=0):
+  c = d.chain[k]
+  c.wp, c.kind = w_img.data_ptr(), kind
+  c.w_scale = _SCALES.get(w_img.data_ptr(), 1.0)
+  c.b = b.data_ptr() if b is not None else None
+  c.out = out.data_ptr() if out is not None else None
+  c.ldo, c.n = ldo, n
+
+
+@pytest.mark.parametrize("n_rows", [64, 200, 1000])
+def test_half_chain_two_row_stages(dev, n_rows):
+  """Node update followed by the next edge update's sender / receiver products (engine: proc_node
+  -> h.W_s, h.W_r; reference typed_graph_net.py:431-453 after the pre-gather split): both chained
+  Linear layers consume the rows the launch stores (LayerNorm output + residual)."""
+  _half_only()
+  rng = np.random.default_rng(n_rows)
+  p = _mlp_ln_case(rng, n_rows, D, D)
+  res = rng.standard_normal((n_rows, D)).astype(np.float32)
+  ws, wr = asymmetric_weight(rng, D, D), asymmetric_weight(rng, D, D)
+  br = (0.2 * rng.standard_normal(D)).astype(np.float32)
+  t = {k: up(v, dev) for k, v in dict(a0=p["a0"], a1=p["a1"], b1=p["b1"], b2=p["b2"], scale=p["scale"],
+                                       offset=p["offset"], res=res, br=br).items()}
+  tw1, tw2, tws, twr = up(pw1(p["w1"]), dev), up(pw2(p["w2"]), dev), up(pw2(ws), dev), up(pw2(wr), dev)
+  out = torch.zeros((n_rows, D), device=dev)
+  o_s = torch.full((n_rows, D + 32), float("nan"), device=dev)           # a wider row stride
+  o_r = torch.zeros((n_rows, D), device=dev)
+  d = new_desc(nat.MODE_MLP_LN, n_rows)
+  d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = t["a0"].data_ptr(), D, D, t["a1"].data_ptr(), D, D
+  d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), t["b1"].data_ptr(), tw2.data_ptr(), t["b2"].data_ptr(), D
+  d.ln_scale, d.ln_offset = t["scale"].data_ptr(), t["offset"].data_ptr()
+  d.res, d.ldres, d.out, d.ldo = t["res"].data_ptr(), D, out.data_ptr(), D
+  d.n_chain = 2
+  _chain_stage(d, 0, tws, nat.CHAIN_ROWS, out=o_s, ldo=D + 32)
+  _chain_stage(d, 1, twr, nat.CHAIN_ROWS, b=t["br"], out=o_r, ldo=D)
+  run(d)
+  h = _mlp_ln_want(p) + res
+  assert_close(out.cpu().numpy(), h, "chain: stored rows")
+  h32 = out.cpu().numpy().astype(np.float64)          # the chain consumes the rows AS STORED (fp32)
+  assert_close(o_s.cpu().numpy()[:, :D], h32 @ ws.astype(np.float64), "chain stage 0 (rows . W_s)")
+  assert torch.isnan(o_s[:, D:]).all()                # nothing written beyond the 512 columns
+  assert_close(o_r.cpu().numpy(), h32 @ wr.astype(np.float64) + br, "chain stage 1 (rows . W_r + b)")
+
+
+@pytest.mark.parametrize("n_rows,n_out", [(64, 227), (333, 83), (500, 240)])
+def test_half_chain_output_mlp(dev, n_rows, n_out):
+  """Decoder node update with the output MLP chained on (engine: dec_node -> swish(h.W1 + b1).W2 + b2,
+  reference deep_typed_graph_net.py:313-322); the node rows themselves are not stored."""
+  _half_only()
+  rng = np.random.default_rng(n_out)
+  p = _mlp_ln_case(rng, n_rows, D, 0)
+  res = rng.standard_normal((n_rows, D)).astype(np.float32)
+  wo1, wo2 = asymmetric_weight(rng, D, D), asymmetric_weight(rng, D, n_out)
+  bo1 = (0.2 * rng.standard_normal(D)).astype(np.float32)
+  bo2 = (0.2 * rng.standard_normal(n_out)).astype(np.float32)
+  t = {k: up(v, dev) for k, v in dict(a0=p["a0"], b1=p["b1"], b2=p["b2"], scale=p["scale"], offset=p["offset"],
+                                       res=res, bo1=bo1, bo2=packing.pad_vector(bo2, 256)).items()}
+  tw1, tw2 = up(pw1(p["w1"]), dev), up(pw2(p["w2"]), dev)
+  two1, two2 = up(pw2(wo1), dev), up(pw2(wo2, np_cols=256), dev)
+  y = torch.full((n_rows, 2, n_out), float("nan"), device=dev)       # batch-strided output rows
+  d = new_desc(nat.MODE_MLP_LN, n_rows)
+  d.a0, d.lda0, d.k0 = t["a0"].data_ptr(), D, D
+  d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), t["b1"].data_ptr(), tw2.data_ptr(), t["b2"].data_ptr(), D
+  d.ln_scale, d.ln_offset = t["scale"].data_ptr(), t["offset"].data_ptr()
+  d.res, d.ldres = t["res"].data_ptr(), D                               # out stays NULL
+  d.n_chain = 2
+  _chain_stage(d, 0, two1, nat.CHAIN_SWISH, b=t["bo1"])
+  c = d.chain[1]
+  c.wp, c.kind, c.w_scale, c.b = two2.data_ptr(), nat.CHAIN_NARROW, _SCALES.get(two2.data_ptr(), 1.0), t["bo2"].data_ptr()
+  c.out, c.ldo, c.n = y.data_ptr() + 4 * n_out, 2 * n_out, n_out       # batch element 1
+  run(d)
+  h = (_mlp_ln_want(p) + res).astype(np.float32).astype(np.float64)
+  hid = ognn.swish(h @ wo1.astype(np.float64) + bo1)
+  want = hid @ wo2.astype(np.float64) + bo2
+  got = y.cpu().numpy()
+  assert np.isnan(got[:, 0]).all()                    # batch element 0 untouched
+  assert_close(got[:, 1], want, "chain: output MLP")
+
+
+def test_half_reads_unaligned_rows_in_place(dev):
+  """The grid embedder reads x[:, b, :448] where it lies (row stride B * 471 floats: 4-byte aligned
+  rows) plus the 32-column tail [x[:, b, 448:] | struct | 0] of gc_prep_grid_tail, instead of the
+  [N, 480] copy of gc_prep_grid_input (reference concat: graphcast.py:561-568)."""
+  _half_only()
+  rng = np.random.default_rng(12)
+  n_rows, batch, c_in, n_struct, b = 333, 2, 471, 3, 1
+  kp, k_full = 480, 448
+  kt = kp - k_full
+  x = rng.standard_normal((n_rows, batch, c_in)).astype(np.float32)
+  st = rng.standard_normal((n_rows, n_struct)).astype(np.float32)
+  w = asymmetric_weight(rng, c_in + n_struct, D)
+  p = dict(b1=(0.3 * rng.standard_normal(D)).astype(np.float32), w2=asymmetric_weight(rng, D, D),
+           b2=(0.3 * rng.standard_normal(D)).astype(np.float32),
+           scale=(1 + 0.2 * rng.standard_normal(D)).astype(np.float32),
+           offset=(0.2 * rng.standard_normal(D)).astype(np.float32))
+  tx, ts = up(x, dev), up(st, dev)
+  xt = torch.full((n_rows, kt), float("nan"), device=dev)
+  lib = nat.lib()
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  nat.check(lib.gc_prep_grid_tail(n_rows, batch, b, c_in, k_full, tx.data_ptr(), n_struct, ts.data_ptr(), kt,
+                                  xt.data_ptr(), stream), "gc_prep_grid_tail")
+  torch.cuda.synchronize()
+  want_tail = np.zeros((n_rows, kt), np.float32)
+  want_tail[:, :c_in - k_full] = x[:, b, k_full:]
+  want_tail[:, c_in - k_full:c_in - k_full + n_struct] = st
+  np.testing.assert_array_equal(xt.cpu().numpy(), want_tail)
+  t = {k: up(v, dev) for k, v in p.items() if k not in ("w2",)}
+  tw1, tw2 = up(pw1(w), dev), up(pw2(p["w2"]), dev)
+  out = torch.zeros((n_rows, D), device=dev)
+  d = new_desc(nat.MODE_MLP_LN, n_rows)
+  d.a0, d.lda0, d.k0 = tx.data_ptr() + 4 * b * c_in, batch * c_in, k_full
+  d.a1, d.lda1, d.k1 = xt.data_ptr(), kt, kt
+  d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), t["b1"].data_ptr(), tw2.data_ptr(), t["b2"].data_ptr(), D
+  d.ln_scale, d.ln_offset = t["scale"].data_ptr(), t["offset"].data_ptr()
+  d.out, d.ldo = out.data_ptr(), D
+  run(d)
+  z = np.concatenate([x[:, b], st], axis=1).astype(np.float64) @ w.astype(np.float64) + p["b1"]
+  want = _ln(ognn.swish(z) @ p["w2"].astype(np.float64) + p["b2"], p["scale"], p["offset"])
+  assert_close(out.cpu().numpy(), want, "in-place unaligned rows + tail")
