@@ -188,6 +188,9 @@ def lib():
                          f"({l.gc_abi_sizeof(0)}/{ctypes.sizeof(RowMlpDesc)}, "
                          f"{l.gc_abi_sizeof(1)}/{ctypes.sizeof(Op)}); rebuild the library")
     l.gc_build_info.restype = ctypes.c_char_p
+    if b"PROFILING_BUILD" in l.gc_build_info():
+      raise RuntimeError(f"{path} is a profiling build (GC_EXP / GC_TRACE): its results may be wrong; "
+                         "rebuild with graphcast_amd._native.build(force=True)")
     _lib = l
   return _lib
 

@@ -55,6 +55,15 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA,
                          // bit3 never wait for the DMA
 
+// Profiling switches that make a kernel compute WRONG results (GC_EXP, CO_EXP: pieces of the work
+// removed) or write timestamps over result buffers (GC_TRACE, CO_TRACE) only compile in a build that
+// says so: scripts/kernel_probe.py / half_probe.py pass -DGC_PROFILING_BUILD, the product build
+// (graphcast_amd/_native.py: build) never does, gc_build_info() reports it and the Python binding
+// refuses to load such a library as the product.
+#if (GC_EXP != 0 || GC_TRACE != 0 || defined(CO_EXP) || defined(CO_TRACE)) && !defined(GC_PROFILING_BUILD)
+#error "GC_EXP / GC_TRACE / CO_EXP / CO_TRACE are profiling-only: compile with -DGC_PROFILING_BUILD"
+#endif
+
 namespace {
 
 constexpr int kD = GC_LATENT;            // 512
@@ -1628,7 +1637,12 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR2(x) #x
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
-  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|3xf16_32x32x16(colown)|bf16_16x16x32;pipe=" GC_STR(GC_PIPE);
+  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|3xf16_32x32x16(colown)|bf16_16x16x32;"
+         "layouts=chunked|colown|half(2wg/cu,chain);pipe=" GC_STR(GC_PIPE)
+#ifdef GC_PROFILING_BUILD
+         ";PROFILING_BUILD(results may be wrong)"
+#endif
+      ;
 }
 
 }  // extern "C"

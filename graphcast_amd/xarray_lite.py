@@ -508,7 +508,9 @@ class DataArray:
       bd = b.data
       if _is_torch(a.data) and not _is_torch(bd):
         import torch
-        bd = torch.as_tensor(np.ascontiguousarray(bd), device=a.data.device)
+        # (np.array: a fresh, writable buffer -- broadcast views / read-only statistics would
+        #  otherwise reach torch as non-writable memory)
+        bd = torch.as_tensor(np.array(bd, order="C"), device=a.data.device)
       coords = dict(getattr(other, "_coords", {}))
       coords.update(self._coords)
       del sizes

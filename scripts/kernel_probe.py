@@ -25,7 +25,7 @@ D = 512
 
 def build(tag, defines):
   out = f"/tmp/libgcast_{tag}.so"
-  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm", *defines,
+  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm", "-DGC_PROFILING_BUILD", *defines,
          "-I", os.path.join(ROOT, "include"), "-shared", "-fPIC",
          os.path.join(ROOT, "graphcast_amd", "csrc", "gcast.hip"), "-o", out]
   subprocess.run(cmd, check=True)
