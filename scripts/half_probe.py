@@ -126,6 +126,13 @@ def main():
     d.out, d.ldo = agg.data_ptr(), 0
     return d, n_e, 2.0 * n_e * 2 * D * D
 
+  def gemm_only_cached_rows(layout):      # the same, every tile reading THE SAME 64 input rows (L2 / L1 hits):
+    d, rows, flop = gemm_only_mlp(layout)  # what the layer-1 row loads' memory latency costs
+    d.n_rows = n_e
+    d.a0 = e.data_ptr()
+    d.lda0 = 0
+    return d, rows, flop
+
   def dec_edge(layout):       # k0 = 0: addends only -> swish -> W2 -> LN -> segment-sum, nothing stored
     d = desc(nat.MODE_MLP_LN, n_e3, layout)
     d.w1_scale = 1.0
@@ -158,7 +165,7 @@ def main():
     d.out, d.ldo = yg.data_ptr(), 227
     return d, n_g, 2.0 * n_g * (D * D + D * 240)
 
-  shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, dec_edge=dec_edge, linear_grid=linear_grid,
+  shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, gemm_only_cached_rows=gemm_only_cached_rows, dec_edge=dec_edge, linear_grid=linear_grid,
                 node_grid=node_grid, dec_out=dec_out)
   only = os.environ.get("PROBE_SHAPES")
   if only:
