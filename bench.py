@@ -281,6 +281,7 @@ def main():
     split = precision == "f16x3"
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
     issue = 3.0 if split else 1.0            # MFMA FLOPs issued per algorithmic FLOP
+    traffic_key = f"{precision}{'h' if getattr(engine, 'half', False) else ''}:{dominant}"
     line = {
         "metric": "6-h rollout steps/sec at 0.25deg/37-level",
         "value": args.gpus * args.steps / elapsed,
@@ -302,7 +303,7 @@ def main():
             "batch_per_gpu": 1},
         "roofline": {
             "bound": "mfma",
-            "kernel": f"{ {'f16x3': 'rowmlpc_kernel' if getattr(engine, 'colown', False) else 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16gemm': 'rowmlpb_kernel'}[precision] }"
+            "kernel": f"{ {'f16x3': 'rowmlpc_kernel' if getattr(engine, 'colown', False) else 'rowmlp16h_kernel' if getattr(engine, 'half', False) else 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16gemm': 'rowmlpb_kernel'}[precision] }"
                       f"<MLP_LN> stage {dominant}",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,
@@ -314,8 +315,8 @@ def main():
                                              issue * achieved / SUSTAINED_F16_MFMA_TFLOPS["mfma_with_operand_streams"]),
             "launches_per_step": dom["launches"],
             "avg_launch_ms": dom["ms"] / dom["launches"],
-            "traffic": (measured_traffic(f"{precision}:{dominant}") or {}).get("bytes_per_launch"),
-            "traffic_source": (measured_traffic(f"{precision}:{dominant}") or {}).get("source"),
+            "traffic": (measured_traffic(traffic_key) or {}).get("bytes_per_launch"),
+            "traffic_source": (measured_traffic(traffic_key) or {}).get("source"),
             "step_executed_tflop": executed_tflop,
             "step_as_written_tflop": f_alg / 1e12,
             "step_frac_executed": executed_tflop / (ms_per_step / 1e3) / peak,
@@ -325,6 +326,9 @@ def main():
         "stages_ms": {k: round(v["ms"], 3) for k, v in sorted(per_stage.items())},
         "setup_seconds": round(t_setup, 1),
         "output_finite": finite,
+        "formulation": ("half-N kernels, two workgroups per CU, chained layers" if getattr(engine, "fuse", False)
+                        else "half-N kernels, two workgroups per CU" if getattr(engine, "half", False)
+                        else "column-owner" if getattr(engine, "colown", False) else "chunked, one workgroup per CU"),
         "build": nat.lib().gc_build_info().decode(),
     }
     if args.gpus == 1 and not args.no_cpu_baseline:

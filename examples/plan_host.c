@@ -97,7 +97,7 @@ int main(void) {
   gc_model_desc m;
   memset(&m, 0, sizeof(m));
   m.n_grid = N_GRID; m.n_mesh = N_MESH; m.c_in = C_IN; m.c_out = C_OUT; m.n_struct = 3;
-  m.num_steps = STEPS; m.prec = GC_PREC_F16X3;
+  m.num_steps = STEPS; m.prec = GC_PREC_F16X3; m.layout = GC_LAYOUT_HALF;
   m.h_grid_node_feat = random_array(N_GRID * 3, 1.0f);
   m.h_mesh_node_feat = random_array(N_MESH * 3, 1.0f);
   m.g2m = make_edges(150, N_GRID, N_MESH);
