@@ -170,6 +170,35 @@ def main():
   only = os.environ.get("PROBE_SHAPES")
   if only:
     shapes = {k: v for k, v in shapes.items() if k in only.split(",")}
+  if os.environ.get("HALF_TRACE"):
+    # phase timeline of wave 0 of every workgroup (GC_H_TRACE build): shader cycles per phase, wall time
+    # per workgroup, how many workgroups ran on each CU
+    lib = build("htrace", ["-DGC_H_TRACE=1"])
+    names = ["prologue_gather", "first_barrier", "layer1", "hidden_pack", "layer2_passes", "scratch_reload_ln",
+             "segsum", "residual_store"]
+    out = {}
+    for name, make in shapes.items():
+      d, rows, flop = make(nat.LAYOUT_HALF)
+      if d.mode != nat.MODE_MLP_LN:
+        continue
+      tiles = (rows + 63) // 64
+      buf = torch.zeros((tiles * 64 * 256 + tiles * 32,), dtype=torch.float32, device=dev)
+      d.scratch = buf.data_ptr()
+      ms = time_launch(lib, d, 3)
+      t = buf[tiles * 64 * 256:].view(torch.int64).view(tiles, 16).cpu().numpy()
+      ph = np.diff(t[:, :9], axis=1).astype(np.float64)
+      row = {"ms": round(ms, 4), "tiles": int(tiles), "wave0_cycles_total_mean": float((t[:, 8] - t[:, 0]).mean())}
+      for j, nme in enumerate(names):
+        row[nme + "_cycles_mean"] = round(float(ph[:, j].mean()), 0)
+      row["wg_wall_us_mean"] = round(float((t[:, 14] - t[:, 12]).mean()) / 100.0, 2)
+      per_cu = np.unique(t[:, 13], return_counts=True)[1]
+      row["workgroups_per_cu_min_max"] = [int(per_cu.min()), int(per_cu.max())]
+      row["shader_ghz_implied"] = round(row["wave0_cycles_total_mean"] / (row["wg_wall_us_mean"] * 1e3), 3)
+      out[name] = row
+      print("htrace", name, json.dumps(row), flush=True)
+    with open(args.out, "w") as f:
+      json.dump(out, f, indent=1)
+    return
   libs = [("chunked", load(nat.library_path()), nat.LAYOUT_CHUNKED), ("half", load(nat.library_path()), nat.LAYOUT_HALF)]
   for spec in filter(None, os.environ.get("HALF_BUILDS", "").split(";")):
     tag, _, defs = spec.partition(":")
