@@ -1406,8 +1406,8 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
     }
     g_h_attr_set[MODE] = true;
   }
-  const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
-  hipLaunchKernelGGL(rowmlp16h_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
+  const int tiles = (d.n_rows + kHRows - 1) / kHRows;
+  hipLaunchKernelGGL(rowmlp16h_kernel<MODE>, dim3(tiles), dim3(64 * GC_H_NW), lds, s, d);
   return check_launch("rowmlp16h_kernel");
 }
 

@@ -97,7 +97,7 @@ def main():
   agg3 = torch.empty((n_gd, D), device=dev)
   partial3 = torch.empty((2 * n_e3 // 64, D), device=dev)
   snd3, rcv3, flags3 = up(pk3.senders), up(pk3.receivers), up(pk3.tile_flags)
-  scratch = torch.empty((max(n_g, n_e, n_e3) + 64, 256), device=dev)
+  scratch = torch.empty((max(n_g, n_e, n_e3) + 128, 256), device=dev)
   prec = nat.PRECISIONS["f16x3"]
   s1 = s2 = float(sc)
 
@@ -211,7 +211,21 @@ def main():
         d, rows, flop = make(layout)
         ms = time_launch(lib, d, args.iters)
         row.setdefault(tag, []).append(ms)
-    out = {}
+    # results of every extra build against the in-tree half-N library (same inputs): max |diff| of `og` / `agg`
+    check = {}
+    if name in ("proc_edge", "node_grid") and len(libs) > 2:
+      def run_once(lib, layout):
+        d, _, _ = make(layout)
+        og.zero_(); agg.zero_()
+        assert lib.gc_rowmlp(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0, lib.gc_last_error()
+        torch.cuda.synchronize()
+        return og.clone(), agg.clone()
+      ref_o, ref_a = run_once(libs[1][1], libs[1][2])
+      for tag, lib, layout in libs[2:]:
+        o, a = run_once(lib, layout)
+        check[tag] = {"out_max_abs_diff": float((o - ref_o).abs().max()), "agg_max_abs_diff": float((a - ref_a).abs().max()),
+                      "out_abs_max": float(ref_o.abs().max())}
+    out = {"_check_vs_in_tree_half": check} if check else {}
     for tag, _, _ in libs:
       ms = float(np.median(row[tag]))
       d, rows, flop = make(nat.LAYOUT_CHUNKED)
