@@ -2,7 +2,7 @@
 """A/B of single gc_rowmlp launches (shapes of the 0.25 deg step): the chunked kernels (one
 workgroup per CU) against the half-N kernels (GC_LAYOUT_HALF, two workgroups per CU), interleaved
 ABAB in one process so that both see the same clocks.  Extra builds of the half kernel can be
-compiled on the spot: HALF_BUILDS="tag:-DX=1,-DY=2;tag2:..."  GPU box only.
+compiled on the spot: HALF_BUILDS="tag:-DX=1,-DY=2;tag2:..." (or tag:@path/to/prebuilt.so).  GPU box only.
 
     python scripts/half_probe.py [--out gpurun_out/half_probe.json] [--iters 20]
 """
@@ -202,7 +202,10 @@ def main():
   libs = [("chunked", load(nat.library_path()), nat.LAYOUT_CHUNKED), ("half", load(nat.library_path()), nat.LAYOUT_HALF)]
   for spec in filter(None, os.environ.get("HALF_BUILDS", "").split(";")):
     tag, _, defs = spec.partition(":")
-    libs.append((tag, build(tag, [x for x in defs.split(",") if x]), nat.LAYOUT_HALF))
+    if defs.startswith("@"):          # a library compiled beforehand (travels with the snapshot): tag:@relative/path.so
+      libs.append((tag, load(os.path.join(ROOT, defs[1:])), nat.LAYOUT_HALF))
+    else:
+      libs.append((tag, build(tag, [x for x in defs.split(",") if x]), nat.LAYOUT_HALF))
   results = {}
   for name, make in shapes.items():
     row = {}
