@@ -173,7 +173,7 @@ def main():
   if os.environ.get("HALF_TRACE"):
     # phase timeline of wave 0 of every workgroup (GC_H_TRACE build): shader cycles per phase, wall time
     # per workgroup, how many workgroups ran on each CU
-    lib = build("htrace", ["-DGC_H_TRACE=1"])
+    lib = build("htrace", ["-DGC_H_TRACE=" + os.environ.get("HALF_TRACE", "1")] + [x for x in os.environ.get("HALF_TRACE_DEFS", "").split(",") if x])
     names = ["prologue_gather", "first_barrier", "layer1", "hidden_pack", "layer2_passes", "scratch_reload_ln",
              "segsum", "residual_store"]
     out = {}
@@ -182,10 +182,10 @@ def main():
       if d.mode != nat.MODE_MLP_LN:
         continue
       tiles = (rows + 63) // 64
-      buf = torch.zeros((tiles * 64 * 256 + tiles * 32,), dtype=torch.float32, device=dev)
+      buf = torch.zeros((tiles * 64 * 256 + tiles * 48,), dtype=torch.float32, device=dev)
       d.scratch = buf.data_ptr()
       ms = time_launch(lib, d, 3)
-      t = buf[tiles * 64 * 256:].view(torch.int64).view(tiles, 16).cpu().numpy()
+      t = buf[tiles * 64 * 256:].view(torch.int64).view(tiles, 24).cpu().numpy()
       ph = np.diff(t[:, :9], axis=1).astype(np.float64)
       row = {"ms": round(ms, 4), "tiles": int(tiles), "wave0_cycles_total_mean": float((t[:, 8] - t[:, 0]).mean())}
       for j, nme in enumerate(names):
@@ -194,6 +194,10 @@ def main():
       per_cu = np.unique(t[:, 13], return_counts=True)[1]
       row["workgroups_per_cu_min_max"] = [int(per_cu.min()), int(per_cu.max())]
       row["shader_ghz_implied"] = round(row["wave0_cycles_total_mean"] / (row["wg_wall_us_mean"] * 1e3), 3)
+      if os.environ.get("HALF_TRACE") == "2":     # cycles of wave 0 at the publishing points (vmcnt wait | barrier)
+        for j, nme in enumerate(["l1_plain_wait", "l1_plain_barrier", "l1_xl_wait", "l1_xl_barrier",
+                                 "l2_wait", "l2_barrier"]):
+          row[nme + "_cycles_mean"] = round(float(t[:, 16 + j].mean()), 0)
       out[name] = row
       print("htrace", name, json.dumps(row), flush=True)
     with open(args.out, "w") as f:
