@@ -107,9 +107,10 @@ EXPORTS = ("gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_p
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
 
-# Build variants of the one source: "main" = the shipped library; "pipe1" = the split-f16 kernels
-# with the per-chunk barrier at the top of each chunk (GC_PIPE=1), kept as an A/B for profiling.
-VARIANTS = {"main": ("libgcast_hip.so", "-DGC_PIPE=2"), "pipe1": ("libgcast_hip_pipe1.so", "-DGC_PIPE=1")}
+# Build variants of the one source: "main" = the shipped library; "ring2" = the half-N kernels with
+# the two-deep ring of 32 KiB sub-chunks (GC_H_R4=0) instead of the four-deep ring of 16 KiB
+# quarters, kept as the A/B baseline (GCAST_LIB_VARIANT=ring2; same results bit for bit).
+VARIANTS = {"main": ("libgcast_hip.so", "-DGC_PIPE=2"), "ring2": ("libgcast_hip_ring2.so", "-DGC_H_R4=0")}
 
 
 def library_path(variant=None):

@@ -1639,6 +1639,13 @@ const char* gc_last_error(void) { return g_err; }
 const char* gc_build_info(void) {
   return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|3xf16_32x32x16(colown)|bf16_16x16x32;"
          "layouts=chunked|colown|half(2wg/cu,chain);pipe=" GC_STR(GC_PIPE)
+#if GC_H_R4 == 1
+         ";ring=4x16k"
+#elif GC_H_R4 == 2
+         ";ring=4x16k(layer1)|2x32k"
+#else
+         ";ring=2x32k"
+#endif
 #ifdef GC_PROFILING_BUILD
          ";PROFILING_BUILD(results may be wrong)"
 #endif

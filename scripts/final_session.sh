@@ -14,6 +14,7 @@ if [ "${DO_TESTS:-1}" = "1" ]; then
   grep -E "passed|failed|FULLSIZE_PARITY|ROLLOUT40_PARITY" "$OUT/pytest_gpu.log" | tail -6 | cut -c1-700
 fi
 echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-20} --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cut -c1-400 "$OUT/bench.json"
+echo "== bench, two-deep ring build (A/B baseline)"; GCAST_LIB_VARIANT=ring2 timeout 600 python bench.py --steps ${BENCH_STEPS:-20} --warmup 5 --no-cpu-baseline > "$OUT/bench_ring2.json" 2>> "$OUT/bench.err"; echo "bench ring2 rc=$?"; cut -c1-260 "$OUT/bench_ring2.json"
 echo "== rocprofv3 kernel trace"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- \
     python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "rocprof rc=$?"

@@ -181,11 +181,12 @@ def main():
       d, rows, flop = make(nat.LAYOUT_HALF)
       if d.mode != nat.MODE_MLP_LN:
         continue
-      tiles = (rows + 63) // 64
-      buf = torch.zeros((tiles * 64 * 256 + tiles * 48,), dtype=torch.float32, device=dev)
+      trows = int(os.environ.get("HALF_TRACE_TILE_ROWS", "64"))       # 128 for a -DGC_H_NW=8 build
+      tiles = (rows + trows - 1) // trows
+      buf = torch.zeros((tiles * trows * 256 + tiles * 48,), dtype=torch.float32, device=dev)
       d.scratch = buf.data_ptr()
       ms = time_launch(lib, d, 3)
-      t = buf[tiles * 64 * 256:].view(torch.int64).view(tiles, 24).cpu().numpy()
+      t = buf[tiles * trows * 256:].view(torch.int64).view(tiles, 24).cpu().numpy()
       ph = np.diff(t[:, :9], axis=1).astype(np.float64)
       row = {"ms": round(ms, 4), "tiles": int(tiles), "wave0_cycles_total_mean": float((t[:, 8] - t[:, 0]).mean())}
       for j, nme in enumerate(names):
