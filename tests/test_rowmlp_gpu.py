@@ -522,3 +522,50 @@ def test_half_reads_unaligned_rows_in_place(dev):
   z = np.concatenate([x[:, b], st], axis=1).astype(np.float64) @ w.astype(np.float64) + p["b1"]
   want = _ln(ognn.swish(z) @ p["w2"].astype(np.float64) + p["b2"], p["scale"], p["offset"])
   assert_close(out.cpu().numpy(), want, "in-place unaligned rows + tail")
+
+
+def test_half_ring_builds_agree_bit_for_bit(dev):
+  """The shipped half-N kernels stream the weights through a four-deep ring of 16 KiB quarter chunks,
+  the `ring2` build variant (graphcast_amd/_native.VARIANTS) through the two-deep ring of 32 KiB
+  sub-chunks of earlier in round 2.  Same MFMAs in the same order per accumulator: the results --
+  rows, chained products, the narrow decoder output -- must be identical to the bit."""
+  _half_only()
+  other = ctypes.CDLL(nat.library_path("ring2"))
+  other.gc_rowmlp.argtypes = [ctypes.POINTER(nat.RowMlpDesc), ctypes.c_void_p]
+  other.gc_rowmlp.restype = ctypes.c_int
+  other.gc_build_info.restype = ctypes.c_char_p
+  assert b"ring=2x32k" in other.gc_build_info()
+  nat.lib().gc_build_info.restype = ctypes.c_char_p
+  assert b"ring=4x16k" in nat.lib().gc_build_info()
+  rng = np.random.default_rng(5)
+  n_rows, n_out = 333, 227
+  p = _mlp_ln_case(rng, n_rows, D, D)
+  res = rng.standard_normal((n_rows, D)).astype(np.float32)
+  ws, wo = asymmetric_weight(rng, D, D), asymmetric_weight(rng, D, n_out)
+  bo = np.zeros(256, np.float32)
+  bo[:n_out] = 0.2 * rng.standard_normal(n_out)
+  t = {k: up(v, dev) for k, v in dict(a0=p["a0"], a1=p["a1"], b1=p["b1"], b2=p["b2"], scale=p["scale"],
+                                       offset=p["offset"], res=res, bo=bo).items()}
+  tw1, tw2, tws, two = up(pw1(p["w1"]), dev), up(pw2(p["w2"]), dev), up(pw2(ws), dev), up(pw2(wo, np_cols=256), dev)
+  results = []
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  for lib in (nat.lib(), other):
+    out = torch.zeros((n_rows, D), device=dev)
+    y = torch.zeros((n_rows, n_out), device=dev)
+    d = new_desc(nat.MODE_MLP_LN, n_rows)
+    d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = t["a0"].data_ptr(), D, D, t["a1"].data_ptr(), D, D
+    d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), t["b1"].data_ptr(), tw2.data_ptr(), t["b2"].data_ptr(), D
+    d.ln_scale, d.ln_offset = t["scale"].data_ptr(), t["offset"].data_ptr()
+    d.res, d.ldres, d.out, d.ldo = t["res"].data_ptr(), D, out.data_ptr(), D
+    d.n_chain = 2
+    _chain_stage(d, 0, tws, nat.CHAIN_SWISH)
+    _chain_stage(d, 1, two, nat.CHAIN_NARROW, b=t["bo"], out=y, ldo=n_out, n=n_out)
+    apply_scales(d)
+    assert lib.gc_rowmlp(ctypes.byref(d), stream) == 0
+    torch.cuda.synchronize()
+    results.append((out.clone(), y.clone()))
+  assert torch.equal(results[0][0], results[1][0])
+  assert torch.equal(results[0][1], results[1][1])
+  h32 = results[0][0].cpu().numpy().astype(np.float64)
+  want = ognn.swish(h32 @ ws.astype(np.float64)) @ wo.astype(np.float64) + bo[:n_out]
+  assert_close(results[0][1].cpu().numpy(), want, "chained output MLP on both ring builds")
