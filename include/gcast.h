@@ -346,7 +346,9 @@ int gc_host_pack_edges(int n_edges, const int* h_senders, const int* h_receivers
 size_t gc_abi_sizeof(int what);
 
 const char* gc_last_error(void);
-/* Build fingerprint: "gfx950;stage=<glds|regs>;..." */
+/* Build fingerprint: "gfx950;tile=64x512;mfma=...;layouts=...;pipe=<1|2>;ring=<4x16k|2x32k>" -- `ring` names the
+ * weight ring of the GC_LAYOUT_HALF kernels (four 16 KiB quarter chunks, or the two 32 KiB sub-chunks of the
+ * "ring2" A/B build); a profiling build appends ";PROFILING_BUILD(...)" and is refused by the Python binding. */
 const char* gc_build_info(void);
 
 #ifdef __cplusplus
