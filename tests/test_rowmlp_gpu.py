@@ -530,6 +530,9 @@ def test_half_ring_builds_agree_bit_for_bit(dev):
   sub-chunks of earlier in round 2.  Same MFMAs in the same order per accumulator: the results --
   rows, chained products, the narrow decoder output -- must be identical to the bit."""
   _half_only()
+  import os
+  if not os.path.exists(nat.library_path("ring2")):
+    nat.build()                                    # (both variants come out of __graft_entry__.build(); hipcc is on the box)
   other = ctypes.CDLL(nat.library_path("ring2"))
   other.gc_rowmlp.argtypes = [ctypes.POINTER(nat.RowMlpDesc), ctypes.c_void_p]
   other.gc_rowmlp.restype = ctypes.c_int
