@@ -87,10 +87,10 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2 };
  *                      j = 0..7: one MFMA A fragment per 1 KiB, fetched with one coalesced
  *                      global_load_dwordx4 per lane.  Same (hi, lo) split, same scales as above.
  *                      Requires k0 <= 512 and k1 in {0, 512} (k1 > 0 only with k0 == 512).
- *   GC_LAYOUT_HALF     (GC_PREC_F16X3, all modes) the CHUNKED images unchanged, streamed as 32 KiB
- *                      sub-chunks (the two 16-n-block halves of a chunk image); layer 2 runs as two
- *                      passes over the output columns with pass 0's accumulators parked in
- *                      `scratch`; <= 256 VGPRs and 66 KiB of LDS per workgroup, so that TWO
+ *   GC_LAYOUT_HALF     (GC_PREC_F16X3, all modes) the CHUNKED images unchanged, streamed as 16 KiB
+ *                      quarter chunks (8 n-blocks of a chunk image) through a four-deep ring; layer 2
+ *                      runs as two passes over the output columns with pass 0's accumulators parked
+ *                      in `scratch`; <= 256 VGPRs and 75 KiB of LDS per workgroup, so that TWO
  *                      workgroups share a CU and one's non-GEMM phases run under the other's MFMAs
  *                      (csrc/rowmlp_half.inc).  MLP_LN launches need `scratch`. */
 enum gc_weight_layout { GC_LAYOUT_CHUNKED = 0, GC_LAYOUT_COLOWN = 1, GC_LAYOUT_HALF = 2 };
