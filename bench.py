@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA peak (same guide; 2:1-sparse figures excluded)
 # What the matrix cores SUSTAIN on this chip with non-zero operands (power-limited clock), measured
-# with scripts/ubench/colown_stream.hip on all 256 CUs, 120-150 ms kernels, random f16 operands:
+# in round 1 with a streaming micro-benchmark on all 256 CUs, 120-150 ms kernels, random f16 operands:
 # bare v_mfma_f32_32x32x16_f16 stream 69 % of peak, with the weight stream from L2 + row fragments
 # from LDS 55 % (profiles/r01_co21_sustained_mfma_random_vs_zero.txt; zero operands: 98 % / 88 %).
 SUSTAINED_F16_MFMA_TFLOPS = {"mfma_only": 0.69 * 2500.0, "mfma_with_operand_streams": 0.55 * 2500.0}
@@ -303,7 +303,7 @@ def main():
             "batch_per_gpu": 1},
         "roofline": {
             "bound": "mfma",
-            "kernel": f"{ {'f16x3': 'rowmlpc_kernel' if getattr(engine, 'colown', False) else 'rowmlp16h_kernel' if getattr(engine, 'half', False) else 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16gemm': 'rowmlpb_kernel'}[precision] }"
+            "kernel": f"{ {'f16x3': 'rowmlp16h_kernel' if getattr(engine, 'half', False) else 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16gemm': 'rowmlpb_kernel'}[precision] }"
                       f"<MLP_LN> stage {dominant}",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,
@@ -326,9 +326,9 @@ def main():
         "stages_ms": {k: round(v["ms"], 3) for k, v in sorted(per_stage.items())},
         "setup_seconds": round(t_setup, 1),
         "output_finite": finite,
-        "formulation": ("half-N kernels, two workgroups per CU, chained layers" if getattr(engine, "fuse", False)
-                        else "half-N kernels, two workgroups per CU" if getattr(engine, "half", False)
-                        else "column-owner" if getattr(engine, "colown", False) else "chunked, one workgroup per CU"),
+        "formulation": ("half-N kernels, two persistent workgroups per CU, chained layers" if getattr(engine, "fuse", False)
+                        else "half-N kernels, two persistent workgroups per CU" if getattr(engine, "half", False)
+                        else "chunked, one workgroup per CU"),
         "build": nat.lib().gc_build_info().decode(),
     }
     if args.gpus == 1 and not args.no_cpu_baseline:

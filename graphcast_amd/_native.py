@@ -16,10 +16,12 @@ MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
 OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_BF16_GEMM = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16gemm": PREC_BF16_GEMM}
-LAYOUT_CHUNKED, LAYOUT_COLOWN, LAYOUT_HALF = 0, 1, 2
+LAYOUT_CHUNKED, LAYOUT_HALF = 0, 2
 LATENT = 512
 TILE_ROWS = 64
 K_CHUNK = 32
+SCRATCH_SLOTS = 512                               # GC_SCRATCH_SLOTS: persistent workgroups of a GC_LAYOUT_HALF launch
+SCRATCH_FLOATS = SCRATCH_SLOTS * TILE_ROWS * 256  # GC_SCRATCH_FLOATS: floats in gc_rowmlp_desc.scratch (32 MiB)
 
 _fp = ctypes.c_void_p     # device pointers travel as integers
 
@@ -107,10 +109,9 @@ EXPORTS = ("gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_p
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
 
-# Build variants of the one source: "main" = the shipped library; "ring2" = the half-N kernels with
-# the two-deep ring of 32 KiB sub-chunks (GC_H_R4=0) instead of the four-deep ring of 16 KiB
-# quarters, kept as the A/B baseline (GCAST_LIB_VARIANT=ring2; same results bit for bit).
-VARIANTS = {"main": ("libgcast_hip.so", "-DGC_PIPE=2"), "ring2": ("libgcast_hip_ring2.so", "-DGC_H_R4=0")}
+# Build variants of the one source: "main" = the shipped library.  Further entries are A/B builds
+# (GCAST_LIB_VARIANT=<name> selects one at load time); only "main" is built by default.
+VARIANTS = {"main": ("libgcast_hip.so", "-DGC_PIPE=2")}
 
 
 def library_path(variant=None):

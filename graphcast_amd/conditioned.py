@@ -63,7 +63,6 @@ class ConditionedEncoderDecoder(engine.StepEngine):
     self.lib = nat.lib()
     precision = precision or engine.DEFAULT_PRECISION
     self.precision, self.prec = precision, nat.PRECISIONS[precision]
-    self.colown = False
     import os
     self.half = (os.environ.get("GCAST_HALF", engine.DEFAULT_HALF) == "1") and self.prec == nat.PREC_F16X3
     self.scratch = None

@@ -55,13 +55,13 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA,
                          // bit3 never wait for the DMA
 
-// Profiling switches that make a kernel compute WRONG results (GC_EXP, CO_EXP: pieces of the work
-// removed) or write timestamps over result buffers (GC_TRACE, CO_TRACE) only compile in a build that
+// Profiling switches that make a kernel compute WRONG results (GC_EXP: pieces of the work
+// removed) or write timestamps over result buffers (GC_TRACE, GC_H_TRACE) only compile in a build that
 // says so: scripts/kernel_probe.py / half_probe.py pass -DGC_PROFILING_BUILD, the product build
 // (graphcast_amd/_native.py: build) never does, gc_build_info() reports it and the Python binding
 // refuses to load such a library as the product.
-#if (GC_EXP != 0 || GC_TRACE != 0 || defined(CO_EXP) || defined(CO_TRACE)) && !defined(GC_PROFILING_BUILD)
-#error "GC_EXP / GC_TRACE / CO_EXP / CO_TRACE are profiling-only: compile with -DGC_PROFILING_BUILD"
+#if (GC_EXP != 0 || GC_TRACE != 0) && !defined(GC_PROFILING_BUILD)
+#error "GC_EXP / GC_TRACE are profiling-only: compile with -DGC_PROFILING_BUILD"
 #endif
 
 namespace {
@@ -504,7 +504,8 @@ __device__ __forceinline__ void init_addends(f4 (&acc)[kNB], const gc_rowmlp_des
   }
 }
 
-__device__ __forceinline__ void store_linear(const f4 (&acc)[kNB], const gc_rowmlp_desc& d, int row, int col0) {
+template <class Desc>
+__device__ __forceinline__ void store_linear(const f4 (&acc)[kNB], const Desc& d, int row, int col0) {
   if (row < d.n_rows) {
     float* o = d.out + (size_t)row * d.ldo + col0;
 #pragma unroll
@@ -981,7 +982,6 @@ __global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d
 #endif
 }
 
-#include "rowmlp_colown.inc"
 #include "rowmlp_half.inc"
 
 // ---- GC_PREC_BF16_GEMM -----------------------------------------------------------------------
@@ -1375,23 +1375,6 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlp_kernel");
 }
 
-bool g_co_attr_set = false;
-
-int launch_rowmlp_colown(const gc_rowmlp_desc& d, hipStream_t s) {
-  if (!g_co_attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpc_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kCoLdsBytes);
-    if (e != hipSuccess) {
-      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%d): %s", kCoLdsBytes, hipGetErrorString(e));
-      return GC_ELAUNCH;
-    }
-    g_co_attr_set = true;
-  }
-  const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
-  hipLaunchKernelGGL(rowmlpc_kernel, dim3(tiles), dim3(256), kCoLdsBytes, s, d);
-  return check_launch("rowmlpc_kernel");
-}
-
 bool g_h_attr_set[3] = {false, false, false};
 
 template <int MODE>
@@ -1406,8 +1389,10 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
     }
     g_h_attr_set[MODE] = true;
   }
+  // persistent workgroups: two per CU on the 256 CUs of an MI355X, each walking tiles b, b + grid, ...
   const int tiles = (d.n_rows + kHRows - 1) / kHRows;
-  hipLaunchKernelGGL(rowmlp16h_kernel<MODE>, dim3(tiles), dim3(64 * GC_H_NW), lds, s, d);
+  const int grid = tiles < GC_SCRATCH_SLOTS ? tiles : GC_SCRATCH_SLOTS;
+  hipLaunchKernelGGL(rowmlp16h_kernel<MODE>, dim3(grid), dim3(256), lds, s, d);
   return check_launch("rowmlp16h_kernel");
 }
 
@@ -1436,7 +1421,7 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
   if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16_GEMM)
     return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
-  if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_COLOWN && d.layout != GC_LAYOUT_HALF)
+  if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_HALF)
     return fail(GC_EINVAL, "gc_rowmlp: unknown weight layout");
   if (d.layout == GC_LAYOUT_HALF) {
     if (d.prec != GC_PREC_F16X3) return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF is built for GC_PREC_F16X3 only");
@@ -1461,12 +1446,6 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
         return fail(GC_EINVAL, "gc_rowmlp: unknown chain kind");
       }
     }
-  }
-  if (d.layout == GC_LAYOUT_COLOWN) {
-    if (d.prec != GC_PREC_F16X3 || d.mode != GC_MODE_MLP_LN)
-      return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_COLOWN is built for GC_PREC_F16X3 + GC_MODE_MLP_LN only");
-    if (d.k0 > 512 || (d.k1 != 0 && (d.k0 != 512 || d.k1 != 512)))
-      return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_COLOWN needs k0 <= 512 and k1 in {0, 512} (k1 only with k0 == 512)");
   }
   if ((d.k0 | d.k1) & 31 || d.k0 < 0 || d.k1 < 0) return fail(GC_EINVAL, "gc_rowmlp: k0/k1 must be multiples of 32");
   if (d.k0 == 0 && d.k1 != 0) return fail(GC_EINVAL, "gc_rowmlp: k1 without k0");
@@ -1500,7 +1479,6 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
       } else if (!d.out && d.n_chain == 0) {
         return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg, no chain)");
       }
-      if (d.layout == GC_LAYOUT_COLOWN) return launch_rowmlp_colown(d, s);
       if (d.layout == GC_LAYOUT_HALF) return launch_rowmlp_half<GC_MODE_MLP_LN>(d, s);
       return launch_rowmlp<GC_MODE_MLP_LN>(d, s);
     case GC_MODE_MLP_OUT:
@@ -1637,15 +1615,8 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR2(x) #x
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
-  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|3xf16_32x32x16(colown)|bf16_16x16x32;"
-         "layouts=chunked|colown|half(2wg/cu,chain);pipe=" GC_STR(GC_PIPE)
-#if GC_H_R4 == 1
-         ";ring=4x16k"
-#elif GC_H_R4 == 2
-         ";ring=4x16k(layer1)|2x32k"
-#else
-         ";ring=2x32k"
-#endif
+  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;"
+         "layouts=chunked|half(2wg/cu,persistent,chain);pipe=" GC_STR(GC_PIPE) ";ring=4x16k"
 #ifdef GC_PROFILING_BUILD
          ";PROFILING_BUILD(results may be wrong)"
 #endif

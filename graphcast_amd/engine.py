@@ -45,12 +45,11 @@ TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, en
 
 
 class _PW:
-  """A packed weight image on the device + the power of two it was multiplied by; `co` is the
-  same matrix in the column-owner layout (GC_LAYOUT_COLOWN), when one was packed."""
-  __slots__ = ("t", "scale", "co")
+  """A packed weight image on the device + the power of two it was multiplied by."""
+  __slots__ = ("t", "scale")
 
-  def __init__(self, t, scale=1.0, co=None):
-    self.t, self.scale, self.co = t, float(scale), co
+  def __init__(self, t, scale=1.0):
+    self.t, self.scale = t, float(scale)
 
   def data_ptr(self):
     return self.t.data_ptr()
@@ -59,7 +58,7 @@ class _PW:
 class _Mlp:
   """Packed device copy of one `<stem>_mlp` (+ `<stem>_layer_norm`)."""
 
-  def __init__(self, params, stem, dev, split=None, np2=D, prec=nat.PREC_F32, colown=False):
+  def __init__(self, params, stem, dev, split=None, np2=D, prec=nat.PREC_F32):
     w1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["w"], dtype=np.float32)
     b1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["b"], dtype=np.float32)
     w2 = np.asarray(params[f"{stem}_mlp/~/linear_1"]["w"], dtype=np.float32)
@@ -73,18 +72,14 @@ class _Mlp:
       # (hi, lo) fp16 images; layer 1 reads rows from memory (natural K order), layer 2 is fed by
       # layer 1's accumulator registers (chained K order) -- include/gcast.h.  Stored as int16
       # bit patterns: the kernels only ever see the raw chunk image.
-      # (both layouts: LINEAR / MLP_OUT launches run the chunked kernels, MLP_LN the column-owner one)
       def pack1(w):
         sc = packing.choose_weight_scale(w)
-        co = up(packing.pack_weight_split_co(w, scale=sc).view(np.int16)) if colown else None
-        return _PW(up(packing.pack_weight_split(w, scale=sc).view(np.int16)), sc, co)
+        return _PW(up(packing.pack_weight_split(w, scale=sc).view(np.int16)), sc)
 
       def pack2(w, np_cols):
         sc = packing.choose_weight_scale(w)
-        co = (up(packing.pack_weight_split_co(w, scale=sc).view(np.int16))
-              if colown and np_cols == D else None)
         return _PW(up(packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc)
-                      .view(np.int16)), sc, co)
+                      .view(np.int16)), sc)
     elif prec == nat.PREC_BF16_GEMM:
       pack1 = lambda w: _PW(up(packing.pack_weight_bf16(w).view(np.int16)))
       pack2 = lambda w, np_cols: _PW(up(packing.pack_weight_bf16(w, np_cols=np_cols, chained=True)
@@ -142,8 +137,7 @@ class StepEngine:
   """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
 
   def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
-               device="cuda:0", precision: Optional[str] = None, colown: Optional[bool] = None,
-               half: Optional[bool] = None):
+               device="cuda:0", precision: Optional[str] = None, half: Optional[bool] = None):
     self.dev = torch.device(device)
     self.lib = nat.lib()
     precision = precision or os.environ.get("GCAST_PRECISION", DEFAULT_PRECISION)
@@ -151,18 +145,12 @@ class StepEngine:
       raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
     self.precision = precision
     self.prec = nat.PRECISIONS[precision]
-    # f16x3 only: `colown=True` / GCAST_COLOWN=1 runs the MLP_LN launches in the column-owner
-    # formulation (csrc/rowmlp_colown.inc).  Opt-in: same results, but on the 0.25 deg step it
-    # measured 4 % slower than the chunked kernels in the same session.
-    if colown is None:
-      colown = os.environ.get("GCAST_COLOWN", "0") == "1"
-    self.colown = bool(colown) and self.prec == nat.PREC_F16X3
     # f16x3 only: `half` / GCAST_HALF selects the half-N formulation for EVERY launch (csrc/
     # rowmlp_half.inc: <= 256 VGPRs and 66 KiB of LDS per workgroup, two workgroups per CU, so one
     # tile's non-GEMM phases run under the other's MFMAs).  Same packed weights as the chunked kernels.
     if half is None:
       half = os.environ.get("GCAST_HALF", DEFAULT_HALF) == "1"
-    self.half = bool(half) and self.prec == nat.PREC_F16X3 and not self.colown
+    self.half = bool(half) and self.prec == nat.PREC_F16X3
     self.scratch = None
     # chained Linear layers + in-place grid input (only the half-N kernels have them); GCAST_FUSE=0
     # keeps one launch per reference layer group for A/B runs
@@ -207,11 +195,9 @@ class StepEngine:
     ds.mode, ds.n_rows, ds.prec = mode, n_rows, self.prec
     ds.a0, ds.k0, ds.lda0 = nat.ptr(a0), k0, (lda0 if lda0 is not None else (a0.shape[1] if a0 is not None else 0))
     ds.a1, ds.k1, ds.lda1 = nat.ptr(a1), k1, (lda1 if lda1 is not None else (a1.shape[1] if a1 is not None else 0))
-    co = (self.colown and mode == nat.MODE_MLP_LN and k0 <= D and k1 in (0, D)
-          and (w1p is None or w1p.co is not None) and w2p is not None and w2p.co is not None)
-    ds.layout = nat.LAYOUT_COLOWN if co else nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED
+    ds.layout = nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED
     if self.half and mode == nat.MODE_MLP_LN:
-      ds.scratch = self._scratch_rows(n_rows).data_ptr()
+      ds.scratch = self._scratch_slots().data_ptr()
     ds.n_chain = len(chain)
     for k, st in enumerate(chain):
       c = ds.chain[k]
@@ -223,12 +209,12 @@ class StepEngine:
         c.out = nat.ptr(st.get("out"))
       c.ldo = st.get("ldo", st["out"].shape[1] if st.get("out") is not None else 0)
       c.n = st.get("n", 0)
-    ds.w1p = nat.ptr(w1p.co if (co and w1p is not None) else w1p)
+    ds.w1p = nat.ptr(w1p)
     ds.w1_scale = w1p.scale if w1p is not None else 1.0
     ds.d, ds.ldd = nat.ptr(d), (d.shape[1] if d is not None else 0)
     ds.g0, ds.idx0, ds.g1, ds.idx1 = nat.ptr(g0), nat.ptr(idx0), nat.ptr(g1), nat.ptr(idx1)
     ds.b1 = nat.ptr(b1)
-    ds.w2p, ds.b2, ds.n2 = nat.ptr(w2p.co if co else w2p), nat.ptr(b2), n2
+    ds.w2p, ds.b2, ds.n2 = nat.ptr(w2p), nat.ptr(b2), n2
     ds.w2_scale = w2p.scale if w2p is not None else 1.0
     if ln is not None:
       ds.ln_scale, ds.ln_offset = nat.ptr(ln[0]), nat.ptr(ln[1])
@@ -240,14 +226,12 @@ class StepEngine:
       ds.agg, ds.partial = nat.ptr(agg), nat.ptr(edges.partial)
     return ds
 
-  def _scratch_rows(self, n_rows):
-    """GC_LAYOUT_HALF: [64 * ceil(n_rows / 64), 256] floats every MLP_LN launch may overwrite (its
-    rows park half of their layer-2 accumulators there between the two column passes).  ONE buffer
-    sized for the largest launch: launches of a step run one after another on one stream."""
-    need = -(-n_rows // packing.TILE) * packing.TILE
-    if self.scratch is None or self.scratch.shape[0] < need:
-      # (a smaller buffer handed to earlier descriptors stays alive in _keep and stays valid)
-      self.scratch = torch.empty((need, 256), dtype=torch.float32, device=self.dev)
+  def _scratch_slots(self):
+    """GC_LAYOUT_HALF: the parking slots of the persistent workgroups (include/gcast.h:
+    gc_rowmlp_desc.scratch) -- 32 MiB whatever the launch sizes are, rewritten by every tile and
+    therefore cache resident; shared by all launches of the engine (they run one after another)."""
+    if self.scratch is None:
+      self.scratch = torch.empty((nat.SCRATCH_FLOATS,), dtype=torch.float32, device=self.dev)
       self._keep.append(self.scratch)
     return self.scratch
 
@@ -287,21 +271,21 @@ class StepEngine:
     M = "mesh_gnn/~_networks_builder/"
     X = "mesh2grid_gnn/~_networks_builder/"
     esr = ("e", "s", "r")
-    self.m_enc_grid = _Mlp(params, G + "encoder_nodes_grid_nodes", dev, prec=self.prec, colown=self.colown)
-    m_enc_mesh = _Mlp(params, G + "encoder_nodes_mesh_nodes", dev, prec=self.prec, colown=self.colown)
-    m_enc_e_g2m = _Mlp(params, G + "encoder_edges_grid2mesh", dev, prec=self.prec, colown=self.colown)
-    self.m_g2m_edge = _Mlp(params, G + "processor_edges_0_grid2mesh", dev, split=esr, prec=self.prec, colown=self.colown)
-    self.m_g2m_mesh = _Mlp(params, G + "processor_nodes_0_mesh_nodes", dev, split=("h", "a"), prec=self.prec, colown=self.colown)
-    self.m_g2m_grid = _Mlp(params, G + "processor_nodes_0_grid_nodes", dev, prec=self.prec, colown=self.colown)
-    m_enc_e_mesh = _Mlp(params, M + "encoder_edges_mesh", dev, prec=self.prec, colown=self.colown)
-    self.m_proc_edge = [_Mlp(params, M + f"processor_edges_{i}_mesh", dev, split=esr, prec=self.prec, colown=self.colown)
+    self.m_enc_grid = _Mlp(params, G + "encoder_nodes_grid_nodes", dev, prec=self.prec)
+    m_enc_mesh = _Mlp(params, G + "encoder_nodes_mesh_nodes", dev, prec=self.prec)
+    m_enc_e_g2m = _Mlp(params, G + "encoder_edges_grid2mesh", dev, prec=self.prec)
+    self.m_g2m_edge = _Mlp(params, G + "processor_edges_0_grid2mesh", dev, split=esr, prec=self.prec)
+    self.m_g2m_mesh = _Mlp(params, G + "processor_nodes_0_mesh_nodes", dev, split=("h", "a"), prec=self.prec)
+    self.m_g2m_grid = _Mlp(params, G + "processor_nodes_0_grid_nodes", dev, prec=self.prec)
+    m_enc_e_mesh = _Mlp(params, M + "encoder_edges_mesh", dev, prec=self.prec)
+    self.m_proc_edge = [_Mlp(params, M + f"processor_edges_{i}_mesh", dev, split=esr, prec=self.prec)
                         for i in range(self.num_steps)]
-    self.m_proc_node = [_Mlp(params, M + f"processor_nodes_{i}_mesh_nodes", dev, prec=self.prec, colown=self.colown)
+    self.m_proc_node = [_Mlp(params, M + f"processor_nodes_{i}_mesh_nodes", dev, prec=self.prec)
                         for i in range(self.num_steps)]
-    m_enc_e_m2g = _Mlp(params, X + "encoder_edges_mesh2grid", dev, prec=self.prec, colown=self.colown)
-    self.m_m2g_edge = _Mlp(params, X + "processor_edges_0_mesh2grid", dev, split=esr, prec=self.prec, colown=self.colown)
-    self.m_m2g_grid = _Mlp(params, X + "processor_nodes_0_grid_nodes", dev, prec=self.prec, colown=self.colown)
-    self.m_out = _Mlp(params, X + "decoder_nodes_grid_nodes", dev, np2=256, prec=self.prec, colown=self.colown)
+    m_enc_e_m2g = _Mlp(params, X + "encoder_edges_mesh2grid", dev, prec=self.prec)
+    self.m_m2g_edge = _Mlp(params, X + "processor_edges_0_mesh2grid", dev, split=esr, prec=self.prec)
+    self.m_m2g_grid = _Mlp(params, X + "processor_nodes_0_grid_nodes", dev, prec=self.prec)
+    self.m_out = _Mlp(params, X + "decoder_nodes_grid_nodes", dev, np2=256, prec=self.prec)
     if self.m_out.n_out != self.c_out:
       raise ValueError(f"decoder produces {self.m_out.n_out} channels, task needs {self.c_out}")
     if self.m_enc_grid.k_in != self.c_in + self.n_struct:

@@ -98,8 +98,8 @@ class GraphCast(predictor_base.Predictor):
 
   def __init__(self, model_config: ModelConfig, task_config: TaskConfig,
                params: Optional[Mapping[str, Mapping[str, Any]]] = None, device: str = "cuda:0",
-               precision: Optional[str] = None, colown: Optional[bool] = None,
-               mesh2grid_face_indices=None, half: Optional[bool] = None):
+               precision: Optional[str] = None, mesh2grid_face_indices=None,
+               half: Optional[bool] = None):
     """``mesh2grid_face_indices``: optional precomputed answer of the reference's
     ``trimesh.Trimesh(...).nearest.on_surface`` query (``utils/legacy/grid_mesh_connectivity.py:
     114-119``) -- the finest-mesh face id containing each grid point, ``[n_lat * n_lon]`` ints in
@@ -115,7 +115,6 @@ class GraphCast(predictor_base.Predictor):
     self._task_config = task_config
     self._device = device
     self._precision = precision       # None -> engine default / GCAST_PRECISION
-    self._colown = colown             # f16x3 only: column-owner MLP_LN kernels (None -> GCAST_COLOWN, default off)
     self._half = half                 # f16x3 only: half-N kernels, two workgroups per CU (None -> GCAST_HALF / engine default)
     self._spatial_features_kwargs = dict(
         add_node_positions=False, add_node_latitude=True, add_node_longitude=True,
@@ -264,7 +263,7 @@ class GraphCast(predictor_base.Predictor):
       self._engine = engine.StepEngine(
           self.graph_arrays(), self._params, num_steps=self._model_config.gnn_msg_steps,
           c_in=c_in, c_out=self._num_outputs, device=self._device, precision=self._precision,
-          colown=self._colown, half=self._half)
+          half=self._half)
     return self._engine
 
   def forward_grid_node_features(self, grid_node_features, out=None):

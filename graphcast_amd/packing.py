@@ -99,40 +99,6 @@ def pack_weight_split(w, np_cols=LATENT, chained=False, scale=1.0):
   return np.ascontiguousarray(out.reshape(kp // K_CHUNK, np_cols // 16, 2, 64, 8)).view(np.uint16)
 
 
-def pack_weight_split_co(w, scale=1.0):
-  """[K, N <= 512] float32 -> uint16 [ceil512(K)/16, 4, 4, 2, 64, 8]: the GC_LAYOUT_COLOWN image of
-  include/gcast.h.  Entry [s, wave, cb, part, 32 g + n, j] = part(hi|lo) of
-  scale * w[16 s + 8 g + j][128 wave + 32 cb + n]: per K=16 step and wave, eight 1 KiB MFMA
-  (32x32x16) A fragments.  K is zero-padded to a multiple of 512 (the kernel runs whole 512-deep
-  passes), N to 512.  Same (hi, lo) split and scale convention as ``pack_weight_split``."""
-  w = np.asarray(w, dtype=np.float32) * np.float32(scale)
-  k, n = w.shape
-  if n > LATENT:
-    raise ValueError(f"weight has {n} columns, the column-owner layout holds {LATENT}")
-  kp = round_up(max(k, 1), LATENT)
-  padded = np.zeros((kp, LATENT), dtype=np.float32)
-  padded[:k, :n] = w
-  hi, lo = split_f16(padded)
-  steps = kp // 16
-  out = np.empty((steps, 4, 4, 2, 2, 32, 8), dtype=np.float16)          # [s, wave, cb, part, g, n, j]
-  for part, src in enumerate((hi, lo)):
-    blk = src.reshape(steps, 2, 8, 4, 4, 32)                             # [s, g, j, wave, cb, n]
-    out[:, :, :, part] = blk.transpose(0, 3, 4, 1, 5, 2)
-  return np.ascontiguousarray(out.reshape(steps, 4, 4, 2, 64, 8)).view(np.uint16)
-
-
-def unpack_weight_split_co(wp, k, n):
-  """Inverse of pack_weight_split_co -> (hi, lo) float32 [k, n] (tests)."""
-  wp = np.asarray(wp).view(np.float16)
-  steps = wp.shape[0]
-  v = wp.reshape(steps, 4, 4, 2, 2, 32, 8).astype(np.float32)           # [s, wave, cb, part, g, n, j]
-  parts = []
-  for part in range(2):
-    full = v[:, :, :, part].transpose(0, 3, 5, 1, 2, 4)                  # [s, g, j, wave, cb, n]
-    parts.append(full.reshape(steps * 16, LATENT)[:k, :n])
-  return parts[0], parts[1]
-
-
 def bf16_bits(x):
   """float32 -> bfloat16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does)."""
   u = np.ascontiguousarray(np.asarray(x, dtype=np.float32)).view(np.uint32)

@@ -53,6 +53,9 @@ extern "C" {
 #define GC_TILE_ROWS 64          /* rows per workgroup tile (4 waves x 16) */
 #define GC_K_CHUNK 32            /* K rows per LDS weight chunk */
 
+#define GC_SCRATCH_SLOTS 512     /* persistent workgroups of a GC_LAYOUT_HALF launch: 2 per CU x 256 CUs */
+#define GC_SCRATCH_FLOATS ((size_t)GC_SCRATCH_SLOTS * GC_TILE_ROWS * 256)   /* floats in gc_rowmlp_desc.scratch */
+
 #define GC_EINVAL (-1)
 #define GC_ELAUNCH (-2)
 
@@ -77,23 +80,15 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2 };
 /* How w1p / w2p are packed, i.e. which tile formulation runs.
  *   GC_LAYOUT_CHUNKED  the layouts described above: 32-row K chunks staged through LDS, every wave
  *                      owns 16 rows of the tile and reads the whole chunk (all modes, all precisions).
- *   GC_LAYOUT_COLOWN   "column owner" (GC_PREC_F16X3 + GC_MODE_MLP_LN only): every wave owns 128
- *                      output columns of the 64-row tile and streams its own weight fragments
- *                      L2 -> registers; rows and hidden activations are shared through LDS; products
- *                      are v_mfma_f32_32x32x16_f16.  A matrix [K, 512] (K zero-padded to a multiple
- *                      of 512) is stored per K=16 step s as
- *                        [s][wave 0..3][column block cb 0..3][hi, lo][lane 0..63][8 halves]   (32 KiB)
- *                      where lane l = 32 g + n holds part(scale * W[16 s + 8 g + j][128 wave + 32 cb + n]),
- *                      j = 0..7: one MFMA A fragment per 1 KiB, fetched with one coalesced
- *                      global_load_dwordx4 per lane.  Same (hi, lo) split, same scales as above.
- *                      Requires k0 <= 512 and k1 in {0, 512} (k1 > 0 only with k0 == 512).
  *   GC_LAYOUT_HALF     (GC_PREC_F16X3, all modes) the CHUNKED images unchanged, streamed as 16 KiB
  *                      quarter chunks (8 n-blocks of a chunk image) through a four-deep ring; layer 2
  *                      runs as two passes over the output columns with pass 0's accumulators parked
  *                      in `scratch`; <= 256 VGPRs and 75 KiB of LDS per workgroup, so that TWO
  *                      workgroups share a CU and one's non-GEMM phases run under the other's MFMAs
- *                      (csrc/rowmlp_half.inc).  MLP_LN launches need `scratch`. */
-enum gc_weight_layout { GC_LAYOUT_CHUNKED = 0, GC_LAYOUT_COLOWN = 1, GC_LAYOUT_HALF = 2 };
+ *                      (csrc/rowmlp_half.inc).  Launches are PERSISTENT: at most GC_SCRATCH_SLOTS
+ *                      workgroups, workgroup b walks the tiles b, b + grid, ...  MLP_LN launches
+ *                      need `scratch`. */
+enum gc_weight_layout { GC_LAYOUT_CHUNKED = 0, /* 1: retired (column-owner formulation, rounds 1-2) */ GC_LAYOUT_HALF = 2 };
 
 /* What a fused row-MLP launch produces. */
 enum gc_rowmlp_mode {
@@ -177,8 +172,10 @@ typedef struct gc_rowmlp_desc {
                                           bit1: last run continues into the next tile */
   float* agg;              /* [n_receivers][512] rows owned entirely by one tile */
   float* partial;          /* [2*n_rows/64][512] straddling partial sums */
-  /* GC_LAYOUT_HALF + GC_MODE_MLP_LN: [64 * ceil(n_rows / 64)][256] floats the launch may overwrite
-   * (every row parks half of its layer-2 accumulators here between the two column passes) */
+  /* GC_LAYOUT_HALF + GC_MODE_MLP_LN: GC_SCRATCH_FLOATS floats (32 MiB, whatever n_rows is) the launch
+   * may overwrite: one 64 KiB slot per persistent workgroup, in which a tile parks half of its
+   * layer-2 accumulators between the two column passes.  Rewritten by every tile: cache resident.
+   * Launches that run one after another on a stream may share it. */
   float* scratch;
   /* GC_LAYOUT_HALF + GC_MODE_MLP_LN, no segment-sum: chained stages (see gc_chain_stage); with a
    * chain `out` may be NULL (the rows are only consumed by the chain) */
@@ -346,9 +343,9 @@ int gc_host_pack_edges(int n_edges, const int* h_senders, const int* h_receivers
 size_t gc_abi_sizeof(int what);
 
 const char* gc_last_error(void);
-/* Build fingerprint: "gfx950;tile=64x512;mfma=...;layouts=...;pipe=<1|2>;ring=<4x16k|2x32k>" -- `ring` names the
- * weight ring of the GC_LAYOUT_HALF kernels (four 16 KiB quarter chunks, or the two 32 KiB sub-chunks of the
- * "ring2" A/B build); a profiling build appends ";PROFILING_BUILD(...)" and is refused by the Python binding. */
+/* Build fingerprint: "gfx950;tile=64x512;mfma=...;layouts=...;pipe=<1|2>;ring=4x16k" -- `ring` names the
+ * weight ring of the GC_LAYOUT_HALF kernels (four 16 KiB quarter chunks); a profiling build appends
+ * ";PROFILING_BUILD(...)" and is refused by the Python binding. */
 const char* gc_build_info(void);
 
 #ifdef __cplusplus

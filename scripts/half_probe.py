@@ -97,7 +97,7 @@ def main():
   agg3 = torch.empty((n_gd, D), device=dev)
   partial3 = torch.empty((2 * n_e3 // 64, D), device=dev)
   snd3, rcv3, flags3 = up(pk3.senders), up(pk3.receivers), up(pk3.tile_flags)
-  scratch = torch.empty((max(n_g, n_e, n_e3) + 128, 256), device=dev)
+  scratch = torch.empty((nat.SCRATCH_FLOATS,), device=dev)       # the persistent workgroups' parking slots
   prec = nat.PRECISIONS["f16x3"]
   s1 = s2 = float(sc)
 
@@ -181,12 +181,11 @@ def main():
       d, rows, flop = make(nat.LAYOUT_HALF)
       if d.mode != nat.MODE_MLP_LN:
         continue
-      trows = int(os.environ.get("HALF_TRACE_TILE_ROWS", "64"))       # 128 for a -DGC_H_NW=8 build
-      tiles = (rows + trows - 1) // trows
-      buf = torch.zeros((tiles * trows * 256 + tiles * 48,), dtype=torch.float32, device=dev)
+      tiles = (rows + 63) // 64
+      buf = torch.zeros((nat.SCRATCH_FLOATS + tiles * 48,), dtype=torch.float32, device=dev)    # slots | 24 x int64 per tile
       d.scratch = buf.data_ptr()
       ms = time_launch(lib, d, 3)
-      t = buf[tiles * trows * 256:].view(torch.int64).view(tiles, 24).cpu().numpy()
+      t = buf[nat.SCRATCH_FLOATS:].view(torch.int64).view(tiles, 24).cpu().numpy()
       ph = np.diff(t[:, :9], axis=1).astype(np.float64)
       row = {"ms": round(ms, 4), "tiles": int(tiles), "wave0_cycles_total_mean": float((t[:, 8] - t[:, 0]).mean())}
       for j, nme in enumerate(names):
@@ -195,10 +194,6 @@ def main():
       per_cu = np.unique(t[:, 13], return_counts=True)[1]
       row["workgroups_per_cu_min_max"] = [int(per_cu.min()), int(per_cu.max())]
       row["shader_ghz_implied"] = round(row["wave0_cycles_total_mean"] / (row["wg_wall_us_mean"] * 1e3), 3)
-      if os.environ.get("HALF_TRACE") == "2":     # cycles of wave 0 at the publishing points (vmcnt wait | barrier)
-        for j, nme in enumerate(["l1_plain_wait", "l1_plain_barrier", "l1_xl_wait", "l1_xl_barrier",
-                                 "l2_wait", "l2_barrier"]):
-          row[nme + "_cycles_mean"] = round(float(t[:, 16 + j].mean()), 0)
       out[name] = row
       print("htrace", name, json.dumps(row), flush=True)
     with open(args.out, "w") as f:

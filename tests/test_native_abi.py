@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built, variant):
     assert hasattr(lib, name), f"{name} missing from {variant} library"
   lib.gc_build_info.restype = ctypes.c_char_p
   info = lib.gc_build_info().decode()
-  assert "gfx950" in info and ("ring=2x32k" if variant == "ring2" else "ring=4x16k") in info
+  assert "gfx950" in info and "ring=4x16k" in info and "persistent" in info
 
 
 def test_struct_layout_matches_header(built):

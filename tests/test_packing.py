@@ -174,29 +174,3 @@ def test_bf16_rounding_and_layout():
       col = 16 * nb + n
       expect = packing.bf16_round(w)[kk, col] if (kk < 474 and col < 227) else 0.0
       assert v[c, nb, 16 * g + n, j] == expect
-
-
-@pytest.mark.parametrize("k,n", [(512, 512), (474, 512), (1024, 512), (32, 512), (4, 300)])
-def test_pack_weight_split_co_round_trip_and_lane_map(k, n):
-  """Column-owner image (GC_LAYOUT_COLOWN): [step][wave][cb][hi, lo][lane 32 g + n][j] holds
-  W[16 step + 8 g + j][128 wave + 32 cb + n]; K padded to whole 512-deep passes, N to 512."""
-  rng = np.random.default_rng(k + n)
-  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
-  sc = packing.choose_weight_scale(w)
-  wp = packing.pack_weight_split_co(w, scale=sc)
-  kp = packing.round_up(k, 512)
-  assert wp.shape == (kp // 16, 4, 4, 2, 64, 8) and wp.dtype == np.uint16 and wp.flags["C_CONTIGUOUS"]
-  hi, lo = packing.unpack_weight_split_co(wp, k, n)
-  want_hi, want_lo = packing.split_f16(w * np.float32(sc))
-  np.testing.assert_array_equal(hi, want_hi.astype(np.float32))
-  np.testing.assert_array_equal(lo, want_lo.astype(np.float32))
-  # one explicit entry: step 3, wave 2, column block 1, lane 32*1 + 5, j = 6
-  kk, col = 16 * 3 + 8 * 1 + 6, 128 * 2 + 32 * 1 + 5
-  if kk < k and col < n:
-    assert wp.view(np.float16)[3, 2, 1, 0, 32 + 5, 6] == want_hi[kk, col]
-    assert wp.view(np.float16)[3, 2, 1, 1, 32 + 5, 6] == want_lo[kk, col]
-  # padding is zero
-  full_hi, _ = packing.unpack_weight_split_co(wp, kp, 512)
-  assert (full_hi[k:] == 0).all() and (full_hi[:, n:] == 0).all()
-  with pytest.raises(ValueError):
-    packing.pack_weight_split_co(np.zeros((8, 513), np.float32))

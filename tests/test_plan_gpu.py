@@ -34,7 +34,7 @@ def test_native_plan_equals_python_plan_bit_for_bit(case, precision, batch):
   half = precision == "f16x3h"
   precision = "f16x3" if half else precision
   kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"], precision=precision, half=half)
-  eng = engine.StepEngine(case["graphs"], case["params"], colown=False, **kw)
+  eng = engine.StepEngine(case["graphs"], case["params"], **kw)
   nat_plan = plan.NativePlan(case["graphs"], case["params"], **kw)
   rng = np.random.default_rng(batch)
   x = torch.from_numpy(rng.standard_normal((case["graphs"]["n_grid"], batch, case["c_in"])).astype(np.float32)).to("cuda:0")

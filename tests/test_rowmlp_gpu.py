@@ -25,19 +25,15 @@ REL_RMSE_TOL = {"f32": 2e-6, "f16x3": 3e-6, "bf16gemm": 5e-5}
 MAX_ABS_TOLS = {"f32": 2e-4, "f16x3": 2e-4, "bf16gemm": 2e-2}
 MAX_ABS_TOL = 2e-4
 _PREC = "f32"          # set per test by the autouse fixture below
-_CO = False            # "f16x3co": the MLP_LN launches run the column-owner formulation (GC_LAYOUT_COLOWN)
 _HALF = False          # "f16x3h": every launch runs the half-N formulation, two workgroups per CU (GC_LAYOUT_HALF)
-_SCRATCH = {}          # keeps the GC_LAYOUT_HALF scratch rows alive until the launch has run
+_SCRATCH = {}          # keeps the GC_LAYOUT_HALF scratch slots alive until the launch has run
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3co", "f16x3h", "bf16gemm"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3h", "bf16gemm"])
 def prec(request):
-  global _PREC, _CO, _HALF
-  _CO = request.param == "f16x3co"
+  global _PREC, _HALF
   _HALF = request.param == "f16x3h"
-  _PREC = "f16x3" if (_CO or _HALF) else request.param
-  if _CO and not any(k in request.node.name for k in ("mlp_ln", "edge_block")):
-    pytest.skip("the column-owner layout only exists for MLP_LN launches")
+  _PREC = "f16x3" if _HALF else request.param
   return _PREC
 
 
@@ -53,8 +49,7 @@ def pw1(w):
   """Layer-1 weight image for the current arithmetic mode."""
   if _PREC == "f16x3":
     sc = packing.choose_weight_scale(w)
-    pack = packing.pack_weight_split_co if _CO else packing.pack_weight_split
-    img = pack(w, scale=sc).view(np.int16).view(Image)
+    img = packing.pack_weight_split(w, scale=sc).view(np.int16).view(Image)
     img.scale = sc
     return img
   if _PREC == "bf16gemm":
@@ -72,10 +67,7 @@ def pw2(w, np_cols=D):
   """Layer-2 weight image (chained K order in split mode)."""
   if _PREC == "f16x3":
     sc = packing.choose_weight_scale(w)
-    if _CO:
-      img = packing.pack_weight_split_co(w, scale=sc).view(np.int16).view(Image)
-    else:
-      img = packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc).view(np.int16).view(Image)
+    img = packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc).view(np.int16).view(Image)
     img.scale = sc
     return img
   if _PREC == "bf16gemm":
@@ -91,12 +83,13 @@ def apply_scales(d):
 def new_desc(mode, n_rows):
   d = nat.RowMlpDesc()
   d.mode, d.n_rows, d.prec = mode, n_rows, nat.PRECISIONS[_PREC]
-  d.layout = nat.LAYOUT_COLOWN if (_CO and mode == nat.MODE_MLP_LN) else nat.LAYOUT_CHUNKED
+  d.layout = nat.LAYOUT_CHUNKED
   if _HALF:
     d.layout = nat.LAYOUT_HALF
     if mode == nat.MODE_MLP_LN:
-      rows = -(-n_rows // 64) * 64
-      _SCRATCH["t"] = torch.full((rows, 256), float("nan"), dtype=torch.float32, device="cuda:0")
+      if "t" not in _SCRATCH:
+        _SCRATCH["t"] = torch.empty((nat.SCRATCH_FLOATS,), dtype=torch.float32, device="cuda:0")
+      _SCRATCH["t"].fill_(float("nan"))
       d.scratch = _SCRATCH["t"].data_ptr()
   return d
 
@@ -244,7 +237,7 @@ def test_mlp_ln_mode_with_residual(dev, n_rows, k0, k1):
   assert torch.equal(inplace, out)
 
 
-@pytest.mark.parametrize("case", ["mesh_like", "skewed", "uniform3", "with_empty"])
+@pytest.mark.parametrize("case", ["mesh_like", "skewed", "uniform3", "with_empty", "many_tiles"])
 def test_edge_block_with_segment_sum(dev, case):
   """The fused edge kernel: gathers -> MLP -> LN -> segment-sum (+fixup, +zero rows)."""
   rng = np.random.default_rng(11)
@@ -255,6 +248,9 @@ def test_edge_block_with_segment_sum(dev, case):
     deg[3], deg[4] = 700, 131
   elif case == "uniform3":
     n_recv, deg = 500, np.full(500, 3)
+  elif case == "many_tiles":          # more tiles than persistent workgroups (GC_SCRATCH_SLOTS)
+    n_recv, deg = 9000, rng.integers(2, 9, 9000)
+    deg[17] = 300
   else:
     n_recv, deg = 200, rng.integers(0, 9, 200)
     deg[0] = deg[199] = 0
@@ -524,24 +520,14 @@ def test_half_reads_unaligned_rows_in_place(dev):
   assert_close(out.cpu().numpy(), want, "in-place unaligned rows + tail")
 
 
-def test_half_ring_builds_agree_bit_for_bit(dev):
-  """The shipped half-N kernels stream the weights through a four-deep ring of 16 KiB quarter chunks,
-  the `ring2` build variant (graphcast_amd/_native.VARIANTS) through the two-deep ring of 32 KiB
-  sub-chunks of earlier in round 2.  Same MFMAs in the same order per accumulator: the results --
-  rows, chained products, the narrow decoder output -- must be identical to the bit."""
+def test_half_persistent_loop_revisits_scratch_slots(dev):
+  """GC_LAYOUT_HALF launches are persistent: at most GC_SCRATCH_SLOTS workgroups walk the tiles
+  (tile, tile + slots, ...), each parking its layer-2 / chain pass-0 accumulators in ITS slot of
+  `scratch`.  More tiles than slots: every slot is rewritten by later tiles (stale parked rows,
+  LayerNorm parameters and biases staged once per workgroup, the weight ring restarted per tile)."""
   _half_only()
-  import os
-  if not os.path.exists(nat.library_path("ring2")):
-    nat.build()                                    # (both variants come out of __graft_entry__.build(); hipcc is on the box)
-  other = ctypes.CDLL(nat.library_path("ring2"))
-  other.gc_rowmlp.argtypes = [ctypes.POINTER(nat.RowMlpDesc), ctypes.c_void_p]
-  other.gc_rowmlp.restype = ctypes.c_int
-  other.gc_build_info.restype = ctypes.c_char_p
-  assert b"ring=2x32k" in other.gc_build_info()
-  nat.lib().gc_build_info.restype = ctypes.c_char_p
-  assert b"ring=4x16k" in nat.lib().gc_build_info()
   rng = np.random.default_rng(5)
-  n_rows, n_out = 333, 227
+  n_rows, n_out = 64 * (nat.SCRATCH_SLOTS + 90) + 5, 227
   p = _mlp_ln_case(rng, n_rows, D, D)
   res = rng.standard_normal((n_rows, D)).astype(np.float32)
   ws, wo = asymmetric_weight(rng, D, D), asymmetric_weight(rng, D, n_out)
@@ -550,25 +536,21 @@ def test_half_ring_builds_agree_bit_for_bit(dev):
   t = {k: up(v, dev) for k, v in dict(a0=p["a0"], a1=p["a1"], b1=p["b1"], b2=p["b2"], scale=p["scale"],
                                        offset=p["offset"], res=res, bo=bo).items()}
   tw1, tw2, tws, two = up(pw1(p["w1"]), dev), up(pw2(p["w2"]), dev), up(pw2(ws), dev), up(pw2(wo, np_cols=256), dev)
-  results = []
-  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-  for lib in (nat.lib(), other):
-    out = torch.zeros((n_rows, D), device=dev)
-    y = torch.zeros((n_rows, n_out), device=dev)
-    d = new_desc(nat.MODE_MLP_LN, n_rows)
-    d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = t["a0"].data_ptr(), D, D, t["a1"].data_ptr(), D, D
-    d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), t["b1"].data_ptr(), tw2.data_ptr(), t["b2"].data_ptr(), D
-    d.ln_scale, d.ln_offset = t["scale"].data_ptr(), t["offset"].data_ptr()
-    d.res, d.ldres, d.out, d.ldo = t["res"].data_ptr(), D, out.data_ptr(), D
-    d.n_chain = 2
-    _chain_stage(d, 0, tws, nat.CHAIN_SWISH)
-    _chain_stage(d, 1, two, nat.CHAIN_NARROW, b=t["bo"], out=y, ldo=n_out, n=n_out)
-    apply_scales(d)
-    assert lib.gc_rowmlp(ctypes.byref(d), stream) == 0
-    torch.cuda.synchronize()
-    results.append((out.clone(), y.clone()))
-  assert torch.equal(results[0][0], results[1][0])
-  assert torch.equal(results[0][1], results[1][1])
-  h32 = results[0][0].cpu().numpy().astype(np.float64)
+  out = torch.zeros((n_rows, D), device=dev)
+  y = torch.zeros((n_rows, n_out), device=dev)
+  d = new_desc(nat.MODE_MLP_LN, n_rows)
+  d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = t["a0"].data_ptr(), D, D, t["a1"].data_ptr(), D, D
+  d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), t["b1"].data_ptr(), tw2.data_ptr(), t["b2"].data_ptr(), D
+  d.ln_scale, d.ln_offset = t["scale"].data_ptr(), t["offset"].data_ptr()
+  d.res, d.ldres, d.out, d.ldo = t["res"].data_ptr(), D, out.data_ptr(), D
+  d.n_chain = 2
+  _chain_stage(d, 0, tws, nat.CHAIN_SWISH)
+  _chain_stage(d, 1, two, nat.CHAIN_NARROW, b=t["bo"], out=y, ldo=n_out, n=n_out)
+  run(d)
+  first = (out.clone(), y.clone())
+  run(d)                                              # bitwise repeatable (no atomics, fixed tile -> slot map)
+  assert torch.equal(first[0], out) and torch.equal(first[1], y)
+  assert_close(out.cpu().numpy(), res.astype(np.float64) + _mlp_ln_want(p), "rows over many tiles per slot")
+  h32 = out.cpu().numpy().astype(np.float64)
   want = ognn.swish(h32 @ ws.astype(np.float64)) @ wo.astype(np.float64) + bo[:n_out]
-  assert_close(results[0][1].cpu().numpy(), want, "chained output MLP on both ring builds")
+  assert_close(y.cpu().numpy(), want, "chained output MLP over many tiles per slot")

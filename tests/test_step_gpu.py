@@ -20,13 +20,12 @@ def rel_rmse(got, want):
   return float(np.linalg.norm(np.asarray(got, np.float64) - want) / np.linalg.norm(want))
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f16x3co", "f16x3h", "f32", "bf16gemm"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3h", "f32", "bf16gemm"])
 def small(request):
-  # "f16x3co": f16x3 arithmetic with the MLP_LN launches in the column-owner formulation;
-  # "f16x3h": every launch in the half-N formulation (two workgroups per CU)
-  colown = request.param == "f16x3co"
+  # "f16x3": the chunked kernels (one workgroup per CU); "f16x3h": every launch in the half-N
+  # formulation (two persistent workgroups per CU) -- the shipped default
   half = request.param == "f16x3h"
-  precision = "f16x3" if (colown or half) else request.param
+  precision = "f16x3" if half else request.param
   if not torch.cuda.is_available():
     pytest.fail("GPU test selected but no GPU is visible")
   res, mesh_size, steps = 4.0, 3, 3
@@ -37,9 +36,9 @@ def small(request):
   c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
   params = oparams.init_params(c_in, c_out, 512, steps, seed=1, nontrivial=True)
   model = gc.GraphCast(cfg, gc.TASK_13, params=params, precision=precision,
-                       colown=colown, half=half).init_from_coordinates(lat, lon)
+                       half=half).init_from_coordinates(lat, lon)
   graphs = ogc.build_graphs(lat, lon, mesh_size)
-  return dict(model=model, precision=precision, colown=colown, graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
+  return dict(model=model, precision=precision, graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
 
 
 def test_product_graphs_equal_oracle_graphs(small):
