@@ -12,9 +12,9 @@ by ``tests/golden/data_utils_ref.npz`` (outputs of the reference module executed
     at lead time 0; inputs are the frames in (-input_duration, 0], targets / forcings the frames
     at the requested lead times (reference :215-362).
 
-Not built: deriving ``toa_incident_solar_radiation`` from orbital mechanics (the reference's
-``solar_radiation.py``, SURVEY.md section 2 row 15: out of scope).  Samples must carry that
-variable, as the published ERA5 / HRES example batches do; ``add_tisr_var`` says so loudly.
+  * ``toa_incident_solar_radiation``, when the sample lacks it, is derived from solar geometry by
+    ``graphcast_amd.solar_radiation`` (the reference's float32 arithmetic, pinned to the reference
+    module's own output) exactly where the reference derives it (reference :184-212).
 """
 from typing import Any, Dict, Sequence, Tuple
 
@@ -84,15 +84,17 @@ def add_derived_vars(data) -> None:
 
 
 def add_tisr_var(data) -> None:
-  """The reference derives a missing ``toa_incident_solar_radiation`` from solar geometry
-  (``solar_radiation.py``); that derivation is out of scope here -- a sample that already has the
-  variable passes through, one that lacks it is rejected."""
+  """Adds ``toa_incident_solar_radiation`` in place when the sample lacks it, derived from the
+  ``datetime`` / ``lat`` / ``lon`` coordinates (reference :184-212).  A batch axis must have length
+  1 (the derivation is per timestamp): longer ones fail in ``squeeze`` like the reference's."""
   if TISR in data.data_vars:
     return
   _require_coords(data, ("datetime", "lat", "lon"))
-  raise NotImplementedError(
-      f"'{TISR}' is not in the sample and deriving it (reference utils/solar_radiation.py) is out of "
-      "scope of the MI355X step: provide it with the data, as the published example batches do")
+  from graphcast_amd import solar_radiation
+  batched = "batch" in data.dims
+  tisr = solar_radiation.get_toa_incident_solar_radiation_for_xarray(
+      data.squeeze("batch") if batched else data, use_jit=True)
+  data.update({TISR: tisr.expand_dims("batch", axis=0) if batched else tisr})
 
 
 # ---------------------------------------------------------------------------- lead-time split

@@ -97,7 +97,10 @@ def main():
   agg3 = torch.empty((n_gd, D), device=dev)
   partial3 = torch.empty((2 * n_e3 // 64, D), device=dev)
   snd3, rcv3, flags3 = up(pk3.senders), up(pk3.receivers), up(pk3.tile_flags)
-  scratch = torch.empty((nat.SCRATCH_FLOATS,), device=dev)       # the persistent workgroups' parking slots
+  # the persistent workgroups' parking slots (HALF_BIG_SCRATCH=1: 1 KiB per row, what a round-2 library
+  # given as HALF_BUILDS=r02:@ab_libs/libgcast_r02.so needs; the shipped kernels use its first 32 MiB)
+  big = os.environ.get("HALF_BIG_SCRATCH") == "1"
+  scratch = torch.empty(((max(n_g, n_e, n_e3) + 128) * 256 if big else nat.SCRATCH_FLOATS,), device=dev)
   prec = nat.PRECISIONS["f16x3"]
   s1 = s2 = float(sc)
 

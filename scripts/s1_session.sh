@@ -11,7 +11,7 @@ echo "== pytest rowmlp + step + plan (gpu)"
 timeout 900 python -m pytest tests/test_rowmlp_gpu.py tests/test_step_gpu.py tests/test_plan_gpu.py -m gpu -x -q --timeout=600 > "$OUT/pytest.log" 2>&1
 echo "pytest rc=$?"; tail -5 "$OUT/pytest.log" | cut -c1-300
 echo "== half_probe"
-timeout 600 python scripts/half_probe.py --rounds 2 --iters 10 --out "$OUT/probe.json" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tee "$OUT/probe.log"
+HALF_BIG_SCRATCH=1 HALF_BUILDS="r02:@ab_libs/libgcast_r02.so" timeout 600 python scripts/half_probe.py --rounds 2 --iters 10 --out "$OUT/probe.json" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tee "$OUT/probe.log"
 echo "== bench"
 timeout 900 python bench.py --steps ${BENCH_STEPS:-20} --warmup 5 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 python -c "
