@@ -1,23 +1,21 @@
-"""Reduced-precision tier next to the fp32-grade step -- and what it is NOT.
+"""Reduced-precision tiers next to the fp32-grade step.
 
 The reference's ``utils/casting.py`` (``Bfloat16Cast`` :31-110, ``bfloat16_variable_view``
 :155-205) casts inputs / forcings to bfloat16, reads the fp32-stored parameters as bfloat16 and
 runs the WHOLE inner predictor in bfloat16: activations between the GEMMs, LayerNorm, residual
 streams and every aggregation except grid2mesh's (``graphcast.py:215``) are bfloat16 values.
 
-That is NOT what is built here, and nothing in this module claims the reference's bf16 numerics:
-
-  * ``Bf16GemmTier`` runs the inner ``GraphCast`` in its ``"bf16gemm"`` arithmetic mode
-    (include/gcast.h ``GC_PREC_BF16_GEMM``): only the GEMM OPERANDS -- weights and the activations
-    entering a matrix product -- are rounded to bfloat16 (nearest even) and multiplied on the bf16
-    matrix cores with fp32 accumulation; bias, gathers, swish, LayerNorm, residuals and all
-    aggregations stay fp32.  Results sit between the reference's bf16 run and its fp32 run.  It is
-    checked against an oracle that rounds the same operands (``oracle.gnn.gemm_operands("bf16")``),
-    not against the fp32 tolerance of the path and not against the reference's bf16 run (which
-    cannot be reproduced here: jax/haiku bf16 semantics are not available offline).
-  * ``Bfloat16Cast`` keeps the reference's NAME and signature so that code written against the
-    reference fails loudly instead of silently getting different numerics: with ``enabled=True``
-    it raises; with ``enabled=False`` it is the reference's pass-through.
+  * ``Bfloat16Cast`` -- the reference's wrapper, same name, signature and role -- runs the inner
+    ``GraphCast`` in its ``"bf16"`` arithmetic (include/gcast.h ``GC_PREC_BF16``,
+    csrc/rowmlp_bf16.inc): bfloat16 parameters, every row tensor of the step bfloat16 in HBM, one
+    bf16 MFMA per product with fp32 accumulation, values rounded to bfloat16 wherever the
+    reference's program materialises an array; LayerNorm's internals and every segment-sum run
+    in fp32.  That is never less accurate than the reference's run but NOT bit-identical to it
+    (XLA's fusion choices and its bfloat16 scatter order cannot be reproduced offline): the tier has
+    its own op-by-op oracle (``oracle/gnn.py``, ``ACTIVATIONS = "bf16"``), marked parity-unpinned.
+  * ``Bf16GemmTier`` runs the ``"bf16gemm"`` mode (``GC_PREC_BF16_GEMM``): only the GEMM OPERANDS are
+    rounded to bfloat16, everything between the GEMMs stays fp32.  Sits between the fp32-grade step
+    and ``Bfloat16Cast``; kept for A/B runs.
 
 numpy has no bfloat16: on host datasets the inputs are rounded *to bfloat16-representable
 float32 values*; torch-backed (HBM-resident) datasets are rounded through ``torch.bfloat16``.
@@ -51,24 +49,29 @@ def to_bfloat16_values(ds: xarray.Dataset) -> xarray.Dataset:
 
 
 @contextlib.contextmanager
-def bf16_gemm_view(predictor):
-  """Runs the innermost engine-backed predictor in the "bf16gemm" arithmetic mode for the
-  duration of the block."""
+def precision_view(predictor, tier):
+  """Runs the innermost engine-backed predictor in arithmetic mode `tier` for the duration of the
+  block (the analogue of the reference's ``bfloat16_variable_view``, casting.py:155-178)."""
   inner = predictor
   while not hasattr(inner, "set_precision") and hasattr(inner, "_predictor"):
     inner = inner._predictor
   if not hasattr(inner, "set_precision"):
-    raise TypeError("Bf16GemmTier needs a predictor built on graphcast_amd.graphcast.GraphCast")
-  prev = inner.set_precision(TIER)
+    raise TypeError("the bfloat16 tiers need a predictor built on graphcast_amd.graphcast.GraphCast")
+  prev = inner.set_precision(tier)
   try:
     yield
   finally:
     inner.set_precision(prev)
 
 
-class Bf16GemmTier(predictor_base.Predictor):
-  """Wrapper: inputs / forcings / predictions rounded to bfloat16 values, the wrapped predictor
-  run with bfloat16 GEMM operands (see the module docstring for what stays fp32)."""
+def bf16_gemm_view(predictor):
+  return precision_view(predictor, TIER)
+
+
+class _Bf16Wrapper(predictor_base.Predictor):
+  """Inputs / forcings / predictions rounded to bfloat16 values (reference ``_all_inputs_to_bfloat16``
+  :126-134 and the cast back to the targets' dtype :61-65), the wrapped predictor run in `_tier`."""
+  _tier = TIER
 
   def __init__(self, predictor: predictor_base.Predictor, enabled: bool = True):
     self._enabled = enabled
@@ -77,7 +80,7 @@ class Bf16GemmTier(predictor_base.Predictor):
   def __call__(self, inputs, targets_template, forcings, **kwargs):
     if not self._enabled:
       return self._predictor(inputs, targets_template, forcings, **kwargs)
-    with bf16_gemm_view(self._predictor):
+    with precision_view(self._predictor, self._tier):
       predictions = self._predictor(to_bfloat16_values(inputs), targets_template,
                                     to_bfloat16_values(forcings), **kwargs)
     return to_bfloat16_values(predictions)
@@ -93,25 +96,12 @@ class Bf16GemmTier(predictor_base.Predictor):
     raise NotImplementedError("inference build: training losses are out of scope")
 
 
-class Bfloat16Cast(predictor_base.Predictor):
-  """The reference's wrapper name (``utils/casting.py:31-65``).  Its semantics -- the whole inner
-  predictor in bfloat16 -- are NOT built: ``enabled=True`` raises and points to ``Bf16GemmTier``;
-  ``enabled=False`` is the reference's pass-through."""
+class Bf16GemmTier(_Bf16Wrapper):
+  """bfloat16 GEMM operands, fp32 everywhere else (``GC_PREC_BF16_GEMM``)."""
+  _tier = TIER
 
-  def __init__(self, predictor: predictor_base.Predictor, enabled: bool = True):
-    if enabled:
-      raise NotImplementedError(
-          "Bfloat16Cast (all activations in bfloat16, reference utils/casting.py:45-65) is not built "
-          "on MI355X: the default path is fp32-grade at 16-bit matrix-core speed.  For bfloat16 GEMM "
-          "operands with fp32 everywhere else use casting.Bf16GemmTier -- its numerics are NOT the "
-          "reference's bf16 run.")
-    self._predictor = predictor
 
-  def __call__(self, inputs, targets_template, forcings, **kwargs):
-    return self._predictor(inputs, targets_template, forcings, **kwargs)
-
-  def loss(self, inputs, targets, forcings, **kwargs):
-    return self._predictor.loss(inputs, targets, forcings, **kwargs)
-
-  def loss_and_predictions(self, inputs, targets, forcings, **kwargs):
-    return self._predictor.loss_and_predictions(inputs, targets, forcings, **kwargs)
+class Bfloat16Cast(_Bf16Wrapper):
+  """The reference's wrapper (``utils/casting.py:31-65``): the inner predictor in bfloat16
+  (``GC_PREC_BF16``; see the module docstring for where this run rounds and where it keeps fp32)."""
+  _tier = "bf16"

@@ -1266,6 +1266,8 @@ __global__ __launch_bounds__(256, 1) void rowmlpb_kernel(const gc_rowmlp_desc d)
 #endif
 }
 
+#include "rowmlp_bf16.inc"
+
 __global__ void seg_fixup_kernel(int n, const int* __restrict__ recv, const int* __restrict__ t0,
                                  const int* __restrict__ t1, const float* __restrict__ partial,
                                  float* __restrict__ agg) {
@@ -1396,7 +1398,76 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlp16h_kernel");
 }
 
+bool g_bf_attr_set[2] = {false, false};
+
+template <bool F32ROWS>
+int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
+  const size_t lds = kHLdsFloats * sizeof(float);
+  if (!g_bf_attr_set[F32ROWS]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpbf_kernel<F32ROWS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+      return GC_ELAUNCH;
+    }
+    g_bf_attr_set[F32ROWS] = true;
+  }
+  const int tiles = (d.n_rows + kHRows - 1) / kHRows;
+  const int grid = tiles < GC_SCRATCH_SLOTS ? tiles : GC_SCRATCH_SLOTS;     // persistent: two workgroups per CU
+  hipLaunchKernelGGL(rowmlpbf_kernel<F32ROWS>, dim3(grid), dim3(256), lds, s, d);
+  return check_launch("rowmlpbf_kernel");
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+// GC_PREC_BF16: MLP_LN launches only (the step's fused program has no others), rows bfloat16 in pi order.
+int rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
+  if (d.layout != GC_LAYOUT_HALF || d.mode != GC_MODE_MLP_LN)
+    return fail(GC_EINVAL, "gc_rowmlp: GC_PREC_BF16 is built for GC_LAYOUT_HALF + GC_MODE_MLP_LN launches");
+  if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
+  if ((d.w1_scale != 0.f && d.w1_scale != 1.f) || (d.w2_scale != 0.f && d.w2_scale != 1.f))
+    return fail(GC_EINVAL, "gc_rowmlp: weight scales are not a GC_PREC_BF16 feature");
+  if ((d.k0 | d.k1) & 31 || d.k0 < 0 || d.k1 < 0) return fail(GC_EINVAL, "gc_rowmlp: k0/k1 must be multiples of 32");
+  if (d.k0 == 0 && d.k1 != 0) return fail(GC_EINVAL, "gc_rowmlp: k1 without k0");
+  if (d.k0 + d.k1 > 0 && (!d.a0 || !d.w1p)) return fail(GC_EINVAL, "gc_rowmlp: layer-1 GEMM needs a0 and w1p");
+  if (d.k1 && !d.a1) return fail(GC_EINVAL, "gc_rowmlp: k1 > 0 needs a1");
+  const bool f32rows = (d.flags & GC_ROWS_F32) != 0;
+  if (!f32rows && ((d.k0 && ((d.lda0 & 7) || !aligned16(d.a0))) || (d.k1 && ((d.lda1 & 7) || !aligned16(d.a1)))))
+    return fail(GC_EINVAL, "gc_rowmlp: bfloat16 rows must be 16-byte aligned (strides multiples of 8 elements)");
+  if ((d.d && ((d.ldd & 7) || !aligned16(d.d))) || !aligned16(d.g0) || !aligned16(d.g1) || !aligned16(d.b1) ||
+      !aligned16(d.w1p) || !aligned16(d.w2p) || !aligned16(d.b2) || !aligned16(d.ln_scale) || !aligned16(d.ln_offset) ||
+      (d.res && ((d.ldres & 7) || !aligned16(d.res))) || (d.out && ((d.ldo & 7) || !aligned16(d.out))) ||
+      !aligned16(d.agg) || !aligned16(d.partial))
+    return fail(GC_EINVAL, "gc_rowmlp: pointers must be 16-byte aligned, bfloat16 row strides multiples of 8");
+  if ((d.g0 && !d.idx0) || (d.g1 && !d.idx1)) return fail(GC_EINVAL, "gc_rowmlp: gather without index array");
+  if (d.k0 + d.k1 == 0 && !d.d && !d.g0 && !d.g1) return fail(GC_EINVAL, "gc_rowmlp: no layer-1 input at all");
+  if (!d.w2p || !d.b2 || d.n2 != kD) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: needs w2p, b2, n2 == 512");
+  if (d.ln_scale && !d.ln_offset) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: ln_scale without ln_offset");
+  if (d.res && !d.out && d.n_chain == 0) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: residual needs out (or a chain)");
+  if (d.n_chain < 0 || d.n_chain > GC_MAX_CHAIN) return fail(GC_EINVAL, "gc_rowmlp: n_chain out of range");
+  if (d.seg) {
+    if (d.n_chain) return fail(GC_EINVAL, "gc_rowmlp: a chain needs a launch without segment-sum");
+    if (d.n_rows % GC_TILE_ROWS) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: segment-sum needs n_rows % 64 == 0");
+    if (!d.tile_flags || !d.agg || !d.partial) return fail(GC_EINVAL, "gc_rowmlp MLP_LN: segment-sum needs tile_flags, agg, partial");
+  } else if (!d.out && d.n_chain == 0) {
+    return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg, no chain)");
+  }
+  for (int k = 0; k < d.n_chain; ++k) {
+    const gc_chain_stage& c = d.chain[k];
+    if (!c.wp || !aligned16(c.wp) || !aligned16(c.b) || (c.w_scale != 0.f && c.w_scale != 1.f))
+      return fail(GC_EINVAL, "gc_rowmlp: chain stage needs 16-byte aligned wp / b (and no weight scale in GC_PREC_BF16)");
+    if (c.kind == GC_CHAIN_ROWS) {
+      if (!c.out || !aligned16(c.out) || (c.ldo & 7)) return fail(GC_EINVAL, "gc_rowmlp: GC_CHAIN_ROWS needs a 16-byte aligned out, ldo % 8 == 0");
+    } else if (c.kind == GC_CHAIN_NARROW) {
+      if (!c.out || c.n <= 0 || c.n > 240) return fail(GC_EINVAL, "gc_rowmlp: GC_CHAIN_NARROW needs out and 0 < n <= 240");
+    } else if (c.kind == GC_CHAIN_SWISH) {
+      if (k + 1 == d.n_chain) return fail(GC_EINVAL, "gc_rowmlp: GC_CHAIN_SWISH must feed a following stage");
+    } else {
+      return fail(GC_EINVAL, "gc_rowmlp: unknown chain kind");
+    }
+  }
+  return f32rows ? launch_rowmlp_bf16<true>(d, s) : launch_rowmlp_bf16<false>(d, s);
+}
 
 }  // namespace
 
@@ -1411,6 +1482,7 @@ static bool pow2_or_unset(float s) {
 int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (!dp) return fail(GC_EINVAL, "gc_rowmlp: null descriptor");
   gc_rowmlp_desc d = *dp;
+  if (d.prec == GC_PREC_BF16) return rowmlp_bf16(d, static_cast<hipStream_t>(stream));
   if (!pow2_or_unset(d.w1_scale) || !pow2_or_unset(d.w2_scale))
     return fail(GC_EINVAL, "gc_rowmlp: w1_scale / w2_scale must be powers of two");
   if (d.w1_scale == 0.f || d.k0 + d.k1 == 0) d.w1_scale = 1.f;   // (no layer-1 weights: nothing is scaled)
@@ -1419,7 +1491,7 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
     return fail(GC_EINVAL, "gc_rowmlp: weight scales are not a GC_PREC_F32 feature");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
-  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16_GEMM)
+  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16_GEMM)   // (GC_PREC_BF16: above)
     return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
   if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_HALF)
     return fail(GC_EINVAL, "gc_rowmlp: unknown weight layout");
@@ -1500,6 +1572,25 @@ int gc_seg_fixup(int n, const int* recv, const int* t0, const int* t1, const flo
   return check_launch("seg_fixup_kernel");
 }
 
+int gc_seg_fixup_bf16(int n, const int* recv, const int* t0, const int* t1, const float* partial, void* agg,
+                      void* stream) {
+  if (n < 0) return fail(GC_EINVAL, "gc_seg_fixup_bf16: negative count");
+  if (n == 0) return 0;
+  if (!recv || !t0 || !t1 || !partial || !agg) return fail(GC_EINVAL, "gc_seg_fixup_bf16: null pointer");
+  hipLaunchKernelGGL(seg_fixup_bf16_kernel, dim3(n), dim3(kD / 2), 0, static_cast<hipStream_t>(stream), n, recv, t0,
+                     t1, partial, static_cast<unsigned*>(agg));
+  return check_launch("seg_fixup_bf16_kernel");
+}
+
+int gc_zero_rows_bf16(int n, const int* rows, void* agg, void* stream) {
+  if (n < 0) return fail(GC_EINVAL, "gc_zero_rows_bf16: negative count");
+  if (n == 0) return 0;
+  if (!rows || !agg) return fail(GC_EINVAL, "gc_zero_rows_bf16: null pointer");
+  hipLaunchKernelGGL(zero_rows_bf16_kernel, dim3(n), dim3(kD / 2), 0, static_cast<hipStream_t>(stream), n, rows,
+                     static_cast<unsigned*>(agg));
+  return check_launch("zero_rows_bf16_kernel");
+}
+
 int gc_zero_rows(int n, const int* rows, float* agg, void* stream) {
   if (n < 0) return fail(GC_EINVAL, "gc_zero_rows: negative count");
   if (n == 0) return 0;
@@ -1555,8 +1646,10 @@ static int run_op(const gc_op& op, void* stream) {
     case GC_OP_ROWMLP:
       return gc_rowmlp(&op.mlp, stream);
     case GC_OP_FIXUP:
+      if (op.mlp.prec == GC_PREC_BF16) return gc_seg_fixup_bf16(op.n, op.i0, op.i1, op.i2, op.src, op.dst, stream);
       return gc_seg_fixup(op.n, op.i0, op.i1, op.i2, op.src, op.dst, stream);
     case GC_OP_ZERO:
+      if (op.mlp.prec == GC_PREC_BF16) return gc_zero_rows_bf16(op.n, op.i0, op.dst, stream);
       return gc_zero_rows(op.n, op.i0, op.dst, stream);
     case GC_OP_PREP:
       if (op.c0 > 0)
@@ -1615,7 +1708,7 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR2(x) #x
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
-  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;"
+  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;tiers=bf16gemm|bf16(Bfloat16Cast);"
          "layouts=chunked|half(2wg/cu,persistent,chain);pipe=" GC_STR(GC_PIPE) ";ring=4x16k"
 #ifdef GC_PROFILING_BUILD
          ";PROFILING_BUILD(results may be wrong)"

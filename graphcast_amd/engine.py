@@ -58,7 +58,7 @@ class _PW:
 class _Mlp:
   """Packed device copy of one `<stem>_mlp` (+ `<stem>_layer_norm`)."""
 
-  def __init__(self, params, stem, dev, split=None, np2=D, prec=nat.PREC_F32):
+  def __init__(self, params, stem, dev, split=None, np2=D, prec=nat.PREC_F32, k_natural=False):
     w1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["w"], dtype=np.float32)
     b1 = np.asarray(params[f"{stem}_mlp/~/linear_0"]["b"], dtype=np.float32)
     w2 = np.asarray(params[f"{stem}_mlp/~/linear_1"]["w"], dtype=np.float32)
@@ -80,6 +80,14 @@ class _Mlp:
         sc = packing.choose_weight_scale(w)
         return _PW(up(packing.pack_weight_split(w, np_cols=np_cols, chained=True, scale=sc)
                       .view(np.int16)), sc)
+    elif prec == nat.PREC_BF16:
+      # GC_PREC_BF16: the bfloat16 view of the fp32-stored parameters (reference casting.py:155-205).  A
+      # matrix whose K operand is a bfloat16 row tensor (pi order == the chained K order) is packed
+      # chained; `k_natural` marks the one fed by external fp32 rows (the grid embedder's first layer).
+      pack1 = lambda w: _PW(up(packing.pack_weight_bf16(w, chained=not k_natural).view(np.int16)))
+      pack2 = lambda w, np_cols: _PW(up(packing.pack_weight_bf16(w, np_cols=np_cols, chained=True)
+                                       .view(np.int16)))
+      b1, b2 = packing.bf16_round(b1), packing.bf16_round(b2)
     elif prec == nat.PREC_BF16_GEMM:
       pack1 = lambda w: _PW(up(packing.pack_weight_bf16(w).view(np.int16)))
       pack2 = lambda w, np_cols: _PW(up(packing.pack_weight_bf16(w, np_cols=np_cols, chained=True)
@@ -102,8 +110,9 @@ class _Mlp:
     self.b2 = up(packing.pad_vector(b2, np2))
     self.scale = self.offset = None
     if f"{stem}_layer_norm" in params:
-      self.scale = up(np.asarray(params[f"{stem}_layer_norm"]["scale"], dtype=np.float32))
-      self.offset = up(np.asarray(params[f"{stem}_layer_norm"]["offset"], dtype=np.float32))
+      vec = packing.bf16_round if prec == nat.PREC_BF16 else (lambda a: a)
+      self.scale = up(vec(np.asarray(params[f"{stem}_layer_norm"]["scale"], dtype=np.float32)))
+      self.offset = up(vec(np.asarray(params[f"{stem}_layer_norm"]["offset"], dtype=np.float32)))
 
 
 class _Edges:
@@ -137,7 +146,8 @@ class StepEngine:
   """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
 
   def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
-               device="cuda:0", precision: Optional[str] = None, half: Optional[bool] = None):
+               device="cuda:0", precision: Optional[str] = None, half: Optional[bool] = None,
+               fold_only: bool = False):
     self.dev = torch.device(device)
     self.lib = nat.lib()
     precision = precision or os.environ.get("GCAST_PRECISION", DEFAULT_PRECISION)
@@ -150,11 +160,11 @@ class StepEngine:
     # tile's non-GEMM phases run under the other's MFMAs).  Same packed weights as the chunked kernels.
     if half is None:
       half = os.environ.get("GCAST_HALF", DEFAULT_HALF) == "1"
-    self.half = bool(half) and self.prec == nat.PREC_F16X3
+    self.half = (bool(half) and self.prec == nat.PREC_F16X3) or self.prec == nat.PREC_BF16
     self.scratch = None
     # chained Linear layers + in-place grid input (only the half-N kernels have them); GCAST_FUSE=0
     # keeps one launch per reference layer group for A/B runs
-    self.fuse = self.half and os.environ.get("GCAST_FUSE", "1") == "1"
+    self.fuse = self.half and (os.environ.get("GCAST_FUSE", "1") == "1" or self.prec == nat.PREC_BF16)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     # Spatially partitioned graphs (partition.plan): node tables that edges GATHER from carry a
     # halo suffix of remote sender rows behind the owned rows; kernels run over the owned prefix
@@ -169,7 +179,10 @@ class StepEngine:
       raise NotImplementedError("decoder width above 240 needs a wider output tile")
     self._stream = None
     self._keep = []            # keeps every tensor referenced by raw pointer alive
-    self._build(graphs, params)
+    if self.prec == nat.PREC_BF16:
+      self._build_bf16(graphs, params)
+    else:
+      self._build(graphs, params, fold_only)
     self._programs: Dict[int, tuple] = {}
     self._cuts: Dict[int, list] = {}
 
@@ -190,13 +203,14 @@ class StepEngine:
   def _desc(self, mode, n_rows, *, a0=None, k0=0, lda0=None, a1=None, k1=0, lda1=None, w1p=None,
             d=None, g0=None, idx0=None, g1=None, idx1=None, b1=None, w2p=None, b2=None, n2=0,
             ln=None, res=None, out=None, ldo=None, out_ptr=None, edges: Optional[_Edges] = None,
-            agg=None, chain=()):
+            agg=None, chain=(), rows_f32=False):
     ds = nat.RowMlpDesc()
+    ds.flags = nat.ROWS_F32 if (rows_f32 and self.prec == nat.PREC_BF16) else 0
     ds.mode, ds.n_rows, ds.prec = mode, n_rows, self.prec
     ds.a0, ds.k0, ds.lda0 = nat.ptr(a0), k0, (lda0 if lda0 is not None else (a0.shape[1] if a0 is not None else 0))
     ds.a1, ds.k1, ds.lda1 = nat.ptr(a1), k1, (lda1 if lda1 is not None else (a1.shape[1] if a1 is not None else 0))
     ds.layout = nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED
-    if self.half and mode == nat.MODE_MLP_LN:
+    if self.half and mode == nat.MODE_MLP_LN and self.prec != nat.PREC_BF16:
       ds.scratch = self._scratch_slots().data_ptr()
     ds.n_chain = len(chain)
     for k, st in enumerate(chain):
@@ -244,12 +258,14 @@ class StepEngine:
     ops = []
     if edges.fix is not None:
       op = nat.Op()
+      op.mlp.prec = self.prec           # (GC_PREC_BF16: bfloat16 aggregate rows)
       op.kind, op.tag, op.n = nat.OP_FIXUP, TAGS["fixup"], edges.fix[0].numel()
       op.i0, op.i1, op.i2 = (nat.ptr(t) for t in edges.fix)
       op.src, op.dst = nat.ptr(edges.partial), nat.ptr(agg)
       ops.append(op)
     if edges.empty is not None:
       op = nat.Op()
+      op.mlp.prec = self.prec
       op.kind, op.tag, op.n = nat.OP_ZERO, TAGS["fixup"], edges.empty.numel()
       op.i0, op.dst = nat.ptr(edges.empty), nat.ptr(agg)
       ops.append(op)
@@ -265,7 +281,7 @@ class StepEngine:
                       ln=(mlp.scale, mlp.offset), **kw)
 
   # ---------------------------------------------------------------- build
-  def _build(self, graphs, params):
+  def _build(self, graphs, params, fold_only=False):
     dev = self.dev
     G = "grid2mesh_gnn/~_networks_builder/"
     M = "mesh_gnn/~_networks_builder/"
@@ -346,6 +362,8 @@ class StepEngine:
     self._keep += [self.h_mesh0, self.d_g2m, self.d_enc_mesh, self.e_mesh0, self.d_mesh0, self.d_m2g,
                    self.e_g2m, self.e_mesh, self.e_m2g]
 
+    if fold_only:             # (Bf16StepEngine's helper: only the folded constants and packed edges are wanted)
+      return
     # ---- per-step workspace ---------------------------------------------------
     self.xin = self._new(ng, self.kp)
     self.h_grid = self._new(ng)         # embedded grid latents, later reused for the decoder update
@@ -357,6 +375,59 @@ class StepEngine:
     self.pre_s_mesh = self._new(self.nm_tab)   # h_mesh.Ws (+ halo rows of remote senders)
     self.pre_r_mesh = self._new(nm)
     self.e_mesh_lat = self._new(self.e_mesh.n_rows)
+
+  def _build_bf16(self, graphs, params):
+    """GC_PREC_BF16 (the reference's Bfloat16Cast run, casting.py:31-65): bfloat16 weights and
+    bfloat16 row tensors in pi order (include/gcast.h).  The input-independent terms are folded by an
+    fp32-grade helper engine (same kernels as the default step) and rounded ONCE to bfloat16 -- the
+    reference recomputes them in bfloat16 every step; ours are the more accurate constants."""
+    dev = self.dev
+    G = "grid2mesh_gnn/~_networks_builder/"
+    M = "mesh_gnn/~_networks_builder/"
+    X = "mesh2grid_gnn/~_networks_builder/"
+    esr = ("e", "s", "r")
+    P = dict(prec=self.prec)
+    self.m_enc_grid = _Mlp(params, G + "encoder_nodes_grid_nodes", dev, k_natural=True, **P)
+    self.m_g2m_edge = _Mlp(params, G + "processor_edges_0_grid2mesh", dev, split=esr, **P)
+    self.m_g2m_mesh = _Mlp(params, G + "processor_nodes_0_mesh_nodes", dev, split=("h", "a"), **P)
+    self.m_g2m_grid = _Mlp(params, G + "processor_nodes_0_grid_nodes", dev, **P)
+    self.m_proc_edge = [_Mlp(params, M + f"processor_edges_{i}_mesh", dev, split=esr, **P) for i in range(self.num_steps)]
+    self.m_proc_node = [_Mlp(params, M + f"processor_nodes_{i}_mesh_nodes", dev, **P) for i in range(self.num_steps)]
+    self.m_m2g_edge = _Mlp(params, X + "processor_edges_0_mesh2grid", dev, split=esr, **P)
+    self.m_m2g_grid = _Mlp(params, X + "processor_nodes_0_grid_nodes", dev, **P)
+    self.m_out = _Mlp(params, X + "decoder_nodes_grid_nodes", dev, np2=256, **P)
+    if self.m_out.n_out != self.c_out:
+      raise ValueError(f"decoder produces {self.m_out.n_out} channels, task needs {self.c_out}")
+    if self.m_enc_grid.k_in != self.c_in + self.n_struct:
+      raise ValueError(f"grid embedder expects {self.m_enc_grid.k_in} input channels, "
+                       f"got {self.c_in} + {self.n_struct} structural")
+    self._keep += [self.m_enc_grid, self.m_g2m_edge, self.m_g2m_mesh, self.m_g2m_grid,
+                   self.m_proc_edge, self.m_proc_node, self.m_m2g_edge, self.m_m2g_grid, self.m_out]
+    base = StepEngine(graphs, params, num_steps=self.num_steps, c_in=self.c_in, c_out=self.c_out,
+                      device=dev, precision="f16x3", half=True, fold_only=True)
+    pi = torch.from_numpy(packing.PI_PERM).to(dev)
+    to_bf = lambda t: t.index_select(1, pi).to(torch.bfloat16).contiguous()
+    self.e_g2m, self.e_mesh, self.e_m2g = base.e_g2m, base.e_mesh, base.e_m2g
+    self.grid_struct = base.grid_struct
+    self.h_mesh0, self.d_g2m, self.d_enc_mesh = to_bf(base.h_mesh0), to_bf(base.d_g2m), to_bf(base.d_enc_mesh)
+    self.e_mesh0, self.d_mesh0, self.d_m2g = to_bf(base.e_mesh0), to_bf(base.d_mesh0), to_bf(base.d_m2g)
+    del base
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    self._keep += [self.h_mesh0, self.d_g2m, self.d_enc_mesh, self.e_mesh0, self.d_mesh0, self.d_m2g,
+                   self.e_g2m, self.e_mesh, self.e_m2g, self.grid_struct]
+    nm, ng = self.n_mesh, self.n_grid
+    new = lambda rows: self._new_bf16(rows)
+    self.xin = self._new(ng, self.kp)            # fp32: the external rows' 32-column tail (gc_prep_grid_tail)
+    self.h_grid, self.pre_grid, self.h_grid2, self.agg_grid = new(ng), new(self.ng_tab), new(ng), new(ng)
+    self.h_mesh, self.agg_mesh = new(nm), new(nm)
+    self.pre_s_mesh, self.pre_r_mesh = new(self.nm_tab), new(nm)
+    self.e_mesh_lat = new(self.e_mesh.n_rows)
+
+  def _new_bf16(self, rows):
+    t = torch.empty((rows, D), dtype=torch.bfloat16, device=self.dev)
+    self._keep.append(t)
+    return t
 
   # ---------------------------------------------------------------- program
   def _program(self, batch):
@@ -481,10 +552,14 @@ class StepEngine:
       ops.append(op)
       # ---- encoder (grid2mesh GNN) ----
       m = self.m_enc_grid
-      x_slots.append((len(ops), "a0", b))
+      if k_full > 0:
+        x_slots.append((len(ops), "a0", b))
+        src = dict(a0=self.xin, k0=k_full, lda0=batch * self.c_in, a1=self.xin, k1=kt, lda1=kt, rows_f32=True)
+      else:                # fewer than 32 input channels: the tail [x | struct | 0] is the whole input
+        src = dict(a0=self.xin, k0=kt, lda0=kt, rows_f32=True)
       ops.append(self._op_mlp("enc_embed_grid", self._mlp_ln(
-          ng, m, a0=self.xin, k0=k_full, lda0=batch * self.c_in, a1=self.xin, k1=kt, lda1=kt,
-          w1p=m.w1, b1=m.b1, out=self.h_grid, chain=[rows(self.m_g2m_edge, "s", self.pre_grid)])))
+          ng, m, w1p=m.w1, b1=m.b1, out=self.h_grid, chain=[rows(self.m_g2m_edge, "s", self.pre_grid)],
+          **src)))
       m = self.m_g2m_edge
       cuts.append((len(ops), "g2m"))
       ops.append(self._op_mlp("enc_edge", self._mlp_ln(

@@ -110,6 +110,28 @@ def bf16_round(x):
   return (bf16_bits(x).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(x))
 
 
+def _pi_perm():
+  """perm[p] = the logical column stored at position p of a GC_PREC_BF16 row (include/gcast.h "pi order":
+  position 32 m + 8 g + 4 b + r holds column 16 (2 m + b) + 4 g + r)."""
+  p = np.arange(LATENT)
+  m, g, b, r = p // 32, (p // 8) % 4, (p // 4) % 2, p % 4
+  return 16 * (2 * m + b) + 4 * g + r
+
+
+PI_PERM = _pi_perm()
+PI_INV = np.argsort(PI_PERM)
+
+
+def to_pi(a):
+  """[..., 512] logical columns -> pi order (works on numpy arrays and torch tensors)."""
+  return a[..., PI_PERM]
+
+
+def from_pi(a):
+  """[..., 512] pi order -> logical columns."""
+  return a[..., PI_INV]
+
+
 def pack_weight_bf16(w, np_cols=LATENT, chained=False):
   """[K, N] float32 -> uint16 [ceil32(K)/32, np_cols/16, 64, 8]: the GC_PREC_BF16_GEMM layout of
   include/gcast.h (the hi-only analogue of ``pack_weight_split``, same K maps)."""

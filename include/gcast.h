@@ -74,8 +74,26 @@ extern "C" {
  *                 (~3e-3 rel-RMSE) and NOT the numerics of the reference's Bfloat16Cast
  *                 (utils/casting.py:45-65 runs the activations in bfloat16 too -- not built);
  *                 weights packed as the hi-only image
- *                 [NP/16 n-blocks][64 lanes][8 bf16] per 32-row K chunk (NP * 64 bytes). */
-enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2 };
+ *                 [NP/16 n-blocks][64 lanes][8 bf16] per 32-row K chunk (NP * 64 bytes).
+ *   GC_PREC_BF16  the TIER that follows the reference's casting.Bfloat16Cast run (utils/casting.py:31-65,
+ *                 155-205; fp32 aggregation only where graphcast.py:215 asks for it is over-fulfilled:
+ *                 every aggregation accumulates in fp32): ALL row tensors -- a0 / a1 (unless
+ *                 GC_ROWS_F32), d, g0, g1, res, out, agg, chained GC_CHAIN_ROWS outputs -- are
+ *                 bfloat16 [rows, 512] in "pi order" (position 32 m + 8 g + 4 b + r holds logical
+ *                 column 16 (2 m + b) + 4 g + r; strides in ELEMENTS, multiples of 8); vectors (b1,
+ *                 b2, LayerNorm, chain biases) stay fp32 [512] in natural order and should hold
+ *                 bfloat16-representable values; `partial` rows are fp32 in pi order; a
+ *                 GC_CHAIN_NARROW output is fp32, natural order, bfloat16-rounded values.  Weights: the
+ *                 GC_PREC_BF16_GEMM image; every matrix whose K operand is a bfloat16 row tensor (or
+ *                 a launch's own rows) in the CHAINED K order, one fed by GC_ROWS_F32 rows in the
+ *                 natural one; no weight scales.  GC_LAYOUT_HALF + GC_MODE_MLP_LN launches only; no
+ *                 `scratch`.  Values are rounded to bfloat16 (nearest even) where the reference's
+ *                 program materialises an array (csrc/rowmlp_bf16.inc); ~1e-2 rel-RMSE from the fp32
+ *                 step -- the reference's own bf16 run is as far away. */
+enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, GC_PREC_BF16 = 3 };
+
+/* gc_rowmlp_desc.flags */
+#define GC_ROWS_F32 1            /* GC_PREC_BF16: a0 / a1 are external fp32 rows in natural column order */
 
 /* How w1p / w2p are packed, i.e. which tile formulation runs.
  *   GC_LAYOUT_CHUNKED  the layouts described above: 32-row K chunks staged through LDS, every wave
@@ -181,6 +199,7 @@ typedef struct gc_rowmlp_desc {
    * chain `out` may be NULL (the rows are only consumed by the chain) */
   int n_chain;
   gc_chain_stage chain[GC_MAX_CHAIN];
+  int flags;               /* GC_ROWS_F32 | ... (0 for everything but GC_PREC_BF16) */
 } gc_rowmlp_desc;
 
 int gc_rowmlp(const gc_rowmlp_desc* desc, void* stream);
@@ -194,6 +213,12 @@ int gc_seg_fixup(int n_entries, const int* recv, const int* t0, const int* t1,
 /* agg[rows[i], :] = 0 for receivers without incoming edges (segment_sum's
  * "zeros for empty segments"). */
 int gc_zero_rows(int n, const int* rows, float* agg, void* stream);
+
+/* The same two for a GC_PREC_BF16 launch: `partial` fp32 rows in pi order, `agg` bfloat16 rows
+ * (gc_run_program picks them for GC_OP_FIXUP / GC_OP_ZERO ops whose mlp.prec is GC_PREC_BF16). */
+int gc_seg_fixup_bf16(int n_entries, const int* recv, const int* t0, const int* t1, const float* partial,
+                      void* agg, void* stream);
+int gc_zero_rows_bf16(int n, const int* rows, void* agg, void* stream);
 
 /* xin[r, :] = [ x[r, b, 0:c_in] | node_struct[r, 0:n_struct] | 0-pad ] (row stride kp).
  * Replaces the concat + batch broadcast of graphcast.py:561-568 for batch

@@ -33,6 +33,8 @@ LN_EPS = 1e-5   # haiku default; no in-tree override (dense.py:182-188)
 
 def swish(x):
   with np.errstate(over="ignore"):      # exp(-x) -> inf gives x / inf = -0.0, the right limit
+    if ACTIVATIONS == "bf16":           # jax.nn.swish = x * sigmoid(x): lax.logistic, then lax.mul
+      return _bf16(x * _bf16(1.0 / (1.0 + np.exp(-x))))
     return x / (1.0 + np.exp(-x))
 
 
@@ -63,11 +65,47 @@ def _bf16(a):
   return r.view(np.float32).astype(np.asarray(a).dtype)
 
 
+# None, or "bf16": the reference's ``casting.Bfloat16Cast`` run (utils/casting.py:31-65,155-205) --
+# inputs, parameters (fp32-stored, read through ``bfloat16_variable_view``) and EVERY array the
+# traced program materialises are bfloat16.  Restated op by op: the result of every jnp / lax
+# operation the reference's Python emits (dot, bias add, logistic, multiply, the six element-wise
+# ops of hk.LayerNorm, residual add, segment_sum) is rounded to bfloat16 (nearest even); dots and
+# the reductions of jnp.mean / jnp.var accumulate in float32 and round once (jax's ``_upcast_f16``
+# computation dtype).  **Parity unpinned**: XLA may fuse element-wise chains and keep float32
+# intermediates inside a fusion, which this op-by-op restatement cannot know; segment_sum in
+# bfloat16 is order dependent in XLA -- here it is a float32 sum rounded once.  Containers stay
+# float32 (numpy has no bfloat16).
+ACTIVATIONS = None
+
+
+class activations:
+  """Context manager: ``with gnn.activations("bf16"): ...`` (run the oracle with dtype=np.float32)."""
+
+  def __init__(self, mode):
+    self.mode = mode
+
+  def __enter__(self):
+    global ACTIVATIONS
+    self.prev, ACTIVATIONS = ACTIVATIONS, self.mode
+
+  def __exit__(self, *exc):
+    global ACTIVATIONS
+    ACTIVATIONS = self.prev
+
+
+def act(x):
+  """Rounds a freshly produced array to the activation dtype (identity unless ACTIVATIONS == "bf16")."""
+  return _bf16(x) if ACTIVATIONS == "bf16" else x
+
+
 def linear(x, w, b):
-  if GEMM_OPERANDS == "bf16":
+  if GEMM_OPERANDS == "bf16" or ACTIVATIONS == "bf16":
     x, w = _bf16(x), _bf16(w)
   # 2-D GEMM: numpy would treat [rows, batch, k] @ [k, n] as `rows` tiny [batch, k] products
-  return (x.reshape(-1, x.shape[-1]) @ w).reshape(x.shape[:-1] + (w.shape[1],)) + b
+  y = (x.reshape(-1, x.shape[-1]) @ w).reshape(x.shape[:-1] + (w.shape[1],))
+  if ACTIVATIONS == "bf16":
+    return _bf16(_bf16(y) + _bf16(b))
+  return y + b
 
 
 def mlp(x, layers):
@@ -82,6 +120,13 @@ def mlp(x, layers):
 def layer_norm(x, scale, offset, eps=LN_EPS):
   mean = x.mean(axis=-1, keepdims=True)
   var = np.square(x - mean).mean(axis=-1, keepdims=True)
+  if ACTIVATIONS == "bf16":
+    # hk.LayerNorm.__call__ as its Python emits it: mean = jnp.mean(x), variance = jnp.var(x) (both
+    # reduced in float32 from the up-cast input, each rounded once), eps cast to the variance's dtype,
+    # inv = scale * lax.rsqrt(variance + eps); return inv * (x - mean) + offset
+    r = _bf16
+    inv = r(r(scale) * r(1.0 / np.sqrt(r(r(var) + r(np.float32(eps))))))
+    return r(r(inv * r(x - r(mean))) + r(offset))
   return (x - mean) / np.sqrt(var + eps) * scale + offset
 
 
@@ -110,7 +155,7 @@ class Net:
 
   def _get(self, module, leaf):
     key = f"{self._g}/~_networks_builder/{module}"
-    return np.asarray(self._p[key][leaf], dtype=self._dt)
+    return act(np.asarray(self._p[key][leaf], dtype=self._dt))      # (bf16 run: the bfloat16 view of the fp32 parameter)
 
   def has(self, name):
     return f"{self._g}/~_networks_builder/{name}_mlp/~/linear_0" in self._p
@@ -165,9 +210,11 @@ def deep_typed_graph_net(params, gnn_name, graph, *, num_steps, embed_nodes,
   ``norm_conditioning`` [batch, C_cond]: the reference's ``use_norm_conditioning=True`` /
   ``global_norm_conditioning`` (see ``Net``).
   """
+  if ACTIVATIONS is not None and (norm_conditioning is not None or np.dtype(dtype) != np.float32):
+    raise ValueError("the bf16-activation restatement runs unconditioned nets with dtype=np.float32")
   net = Net(params, gnn_name, dtype, norm_conditioning=norm_conditioning)
-  nodes = {k: np.asarray(v, dtype=dtype) for k, v in graph["nodes"].items()}
-  edges = {k: dict(v, features=np.asarray(v["features"], dtype=dtype))
+  nodes = {k: act(np.asarray(v, dtype=dtype)) for k, v in graph["nodes"].items()}
+  edges = {k: dict(v, features=act(np.asarray(v["features"], dtype=dtype)))
            for k, v in graph["edges"].items()}
 
   # _embed (deep_typed_graph_net.py:325-353)
@@ -188,19 +235,19 @@ def deep_typed_graph_net(params, gnn_name, graph, *, num_steps, embed_nodes,
       if last and live_nodes is not None and k not in live_nodes:
         continue
       agg_in = (lambda a: a.astype(np.float32)) if f32_aggregation else (lambda a: a)
-      received = [segment_sum(agg_in(new_edges[ek]), e["receivers"], h.shape[0]).astype(dtype)
+      received = [act(segment_sum(agg_in(new_edges[ek]), e["receivers"], h.shape[0]).astype(dtype))
                   for ek, e in sorted(edges.items()) if e["receivers_set"] == k]
       new_nodes[k] = net.apply(f"processor_nodes_{step}_{k}", h, *received)
     for k in list(nodes):
       if k in new_nodes:
-        nodes[k] = nodes[k] + new_nodes[k]
+        nodes[k] = act(nodes[k] + new_nodes[k])
       else:
         del nodes[k]
     for k, e in edges.items():
       if last and live_edges is not None and k not in live_edges:
         e["features"] = None
       else:
-        e["features"] = e["features"] + new_edges[k]
+        e["features"] = act(e["features"] + new_edges[k])
 
   # _output (:395-401)
   for k in node_output:

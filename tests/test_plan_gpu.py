@@ -64,3 +64,29 @@ def test_native_plan_rejects_bad_inputs(case):
   with pytest.raises(ValueError):
     p(torch.zeros((5, 1, case["c_in"]), device="cuda:0"))
   p.close()
+
+
+@pytest.mark.parametrize("c_in", [20, 29, 32])
+def test_fewer_than_32_input_channels(c_in):
+  """The fused program reads x[:, b, :32 * (c_in // 32)] in place and a 32-column tail: with fewer
+  than 32 channels there is no in-place part and the tail IS the input (used to fail
+  with 'k1 without k0' in the default configuration).  Engine == native plan == float64 oracle."""
+  res, mesh_size, steps = 6.0, 2, 1
+  lat = np.arange(-90, 90 + res / 2, res)
+  lon = np.arange(0, 360, res)
+  graphs = ogc.build_graphs(lat, lon, mesh_size)
+  c_out = 7
+  params = oparams.init_params(c_in, c_out, 512, steps, seed=4, nontrivial=True)
+  kw = dict(num_steps=steps, c_in=c_in, c_out=c_out)
+  x = torch.from_numpy(np.random.default_rng(c_in).standard_normal((graphs["n_grid"], 2, c_in)).astype(np.float32)).to("cuda:0")
+  eng = engine.StepEngine(graphs, params, **kw)
+  assert eng.half and eng.fuse
+  want = eng(x)
+  nat_plan = plan.NativePlan(graphs, params, **kw)
+  got = nat_plan(x)
+  torch.cuda.synchronize()
+  assert torch.equal(got, want)
+  ref = ogc.forward(params, graphs, x.cpu().numpy(), steps=steps, dtype=np.float64)
+  err = float(np.linalg.norm(got.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref))
+  assert err <= 2e-5, err
+  nat_plan.close()
