@@ -116,7 +116,7 @@ def _time_step(backend, params, graphs, x, steps):
   return time.perf_counter() - t0
 
 
-def cpu_baseline(c_in, c_out, steps, f_full, full_graphs=None, full_x=None, budget_s=40.0):
+def cpu_baseline(c_in, c_out, steps, f_full, full_graphs=None, full_x=None, budget_s=240.0):
   """Times the CPU restatement of the reference step (fp32, as written: concat -> MLP -> LayerNorm,
   scatter-add; JAX is not installable) on the GPU box's host cores.
 
@@ -138,7 +138,8 @@ def cpu_baseline(c_in, c_out, steps, f_full, full_graphs=None, full_x=None, budg
   secs["torch"] = _time_step("torch", params, graphs, x, steps)
   rates["torch"] = f_sample / secs["torch"] / 1e9
   _time_step("numpy", params, warm_graphs, warm_x, steps)
-  secs["numpy"] = _time_step("numpy", params, graphs, x, steps) if secs["torch"] < 30.0 else None
+  # (the numpy back end is only timed when the whole leg stays bounded: the full step below is the value)
+  secs["numpy"] = _time_step("numpy", params, graphs, x, steps) if secs["torch"] < 12.0 else None
   rates["numpy"] = f_sample / secs["numpy"] / 1e9 if secs["numpy"] else None
   best = "torch" if (rates["numpy"] is None or rates["torch"] >= rates["numpy"]) else "numpy"
   est_full = secs[best] * f_full / f_sample
@@ -322,8 +323,15 @@ def main():
             "step_executed_tflop": executed_tflop,
             "step_as_written_tflop": f_alg / 1e12,
             "step_frac_executed": executed_tflop / (ms_per_step / 1e3) / peak,
-            "step_frac_as_written": f_alg / 1e12 / (ms_per_step / 1e3) / peak},
+            "step_frac_as_written": f_alg / 1e12 / (ms_per_step / 1e3) / peak,
+            # every stage against the same peak (executed FLOPs of its launches / its HIP-event time)
+            "stages": {k: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflop": round(v["tflop"], 4),
+                           "achieved": (v["tflop"] / (v["ms"] / 1e3) if v["ms"] > 0 else 0.0),
+                           "frac": (v["tflop"] / (v["ms"] / 1e3) / peak if v["ms"] > 0 else 0.0)}
+                       for k, v in sorted(per_stage.items()) if v["tflop"] > 0}},
         "precision": precision,
+        "tier": (None if precision in ("f16x3", "f32") else
+                 "reduced-precision TIER line: the headline is the default f16x3 run (fp32-grade results)"),
         "cross_check": cross,
         "stages_ms": {k: round(v["ms"], 3) for k, v in sorted(per_stage.items())},
         "setup_seconds": round(t_setup, 1),

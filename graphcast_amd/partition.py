@@ -1,6 +1,8 @@
 """Spatial partition of the three GraphCast graphs across GPUs (BASELINE.json config 5).
 
-Nodes (grid nodes and mesh nodes) are split into P parts by longitude band; every edge belongs
+Nodes (grid nodes and mesh nodes) are split into P compact regions (hemispheres / quadrants /
+OCTANTS by the signs of the unit-sphere coordinates for P = 2 / 4 / 8, equal-count longitude bands
+otherwise); every edge belongs
 to the **owner of its receiver**, so the receiver aggregation (``jraph.segment_sum``,
 ``typed_graph_net.py:532-538``) is local to a rank -- the "shard-local => drop the collective"
 case of the reference's own sharded ops (``gather_scatter_ops.py:102-144``).  What a rank needs
@@ -10,9 +12,11 @@ from others are *sender* rows only:
   processor : ``(h_mesh . W_s)`` rows of remote mesh senders, every message-passing step (16)
   decoder   : ``(h_mesh . W_s)`` rows of remote mesh senders of its grid nodes          (1)
 
-i.e. 18 halo exchanges per 6-h step of 512-float rows (SURVEY.md 8e measured ~0.9 MB per rank
-per processor step at 0.25 deg / 8 parts: latency-bound, so each exchange is ONE
-``all_to_all_single`` with precomputed split sizes).
+i.e. 18 halo exchanges per 6-h step of 512-float rows.  Measured at 0.25 deg / 8 parts (this plan,
+round 3): octants 393-466 remote sender rows per rank and processor step (mean 419 = 0.86 MB; the
+figures SURVEY.md 8e predicted), 770-5,540 grid rows once for the encoder, 200-278 mesh rows once
+for the decoder; longitude bands 522-592 / 3,483-7,768 / 266-339.  Latency-bound, so each exchange
+is ONE ``all_to_all_single`` with precomputed split sizes.
 
 Local index space of a rank, per node set: ``[owned nodes (global order) | halo nodes (grouped by
 owner rank, global order within a group)]``.  Kernels run over the owned prefix; an exchange
@@ -56,6 +60,26 @@ def owner_by_longitude(lon_deg: np.ndarray, n_parts: int) -> np.ndarray:
   return owner
 
 
+def owner_by_octant(lat_deg: np.ndarray, lon_deg: np.ndarray, n_parts: int) -> np.ndarray:
+  """Compact equal-area regions for n_parts in {1, 2, 4, 8}: the part of a node is read off the signs
+  of its unit-sphere coordinates -- (x) hemispheres, (x, y) quadrants (lunes), (x, y, z) octants --
+  the partition SURVEY.md section 8e measured (octants: 2.65 % of the multi-mesh edges cross parts,
+  393-466 remote sender rows per rank and processor step at 0.25 deg, against 520-590 for the eight
+  longitude bands, whose slivers all meet at both poles).  Nodes exactly on a dividing plane go to the
+  non-negative side, so grid and mesh nodes at the same place agree."""
+  if n_parts not in (1, 2, 4, 8):
+    raise ValueError("sign-based regions exist for 1, 2, 4 or 8 parts")
+  lat = np.radians(np.asarray(lat_deg, dtype=np.float64))
+  lon = np.radians(np.asarray(lon_deg, dtype=np.float64))
+  x, y, z = np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)
+  tiny = 1e-12                                          # (cos(90 deg) is 6e-17, not 0: snap it)
+  bits = [(v < -tiny).astype(np.int32) for v in (x, y, z)]
+  owner = np.zeros(len(lat), dtype=np.int32)
+  for k in range({1: 0, 2: 1, 4: 2, 8: 3}[n_parts]):
+    owner |= bits[k] << k
+  return owner
+
+
 def _halo(senders, receivers, send_owner, recv_owner, rank, n_parts):
   """Remote senders of the edges whose receiver `rank` owns."""
   mine = recv_owner[receivers] == rank
@@ -66,13 +90,20 @@ def _halo(senders, receivers, send_owner, recv_owner, rank, n_parts):
   return halo_global.astype(np.int64), np.array([len(g) for g in groups], dtype=np.int64)
 
 
-def plan(graphs: dict, grid_lon: np.ndarray, mesh_lon: np.ndarray, n_parts: int) -> List[RankGraphs]:
+def plan(graphs: dict, grid_lon: np.ndarray, mesh_lon: np.ndarray, n_parts: int, *,
+         grid_lat: np.ndarray = None, mesh_lat: np.ndarray = None) -> List[RankGraphs]:
   """Splits ``GraphCast.graph_arrays()`` into per-rank local graphs + halo plans.
 
-  ``grid_lon`` / ``mesh_lon``: longitude (degrees) of every grid / mesh node."""
+  ``grid_lon`` / ``mesh_lon``: longitude (degrees) of every grid / mesh node.  With the latitudes
+  given as well and 2, 4 or 8 parts the regions are hemispheres / quadrants / OCTANTS
+  (``owner_by_octant``); otherwise equal-count longitude bands."""
   n_grid, n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
-  g_owner = owner_by_longitude(grid_lon, n_parts)
-  m_owner = owner_by_longitude(mesh_lon, n_parts)
+  if grid_lat is not None and mesh_lat is not None and n_parts in (2, 4, 8):
+    g_owner = owner_by_octant(grid_lat, grid_lon, n_parts)
+    m_owner = owner_by_octant(mesh_lat, mesh_lon, n_parts)
+  else:
+    g_owner = owner_by_longitude(grid_lon, n_parts)
+    m_owner = owner_by_longitude(mesh_lon, n_parts)
   g_owned = [np.flatnonzero(g_owner == p) for p in range(n_parts)]
   m_owned = [np.flatnonzero(m_owner == p) for p in range(n_parts)]
   g2m, mesh, m2g = graphs["g2m"], graphs["mesh"], graphs["m2g"]
@@ -212,9 +243,9 @@ class EmulatedPartitionedStep:
   points); it exists to validate config 5 on a single MI355X and in CI."""
 
   def __init__(self, graphs: dict, params, grid_lon, mesh_lon, n_parts: int, *, num_steps: int,
-               c_in: int, c_out: int, device="cuda:0", precision=None):
+               c_in: int, c_out: int, device="cuda:0", precision=None, grid_lat=None, mesh_lat=None):
     from graphcast_amd import engine
-    self.ranks = plan(graphs, grid_lon, mesh_lon, n_parts)
+    self.ranks = plan(graphs, grid_lon, mesh_lon, n_parts, grid_lat=grid_lat, mesh_lat=mesh_lat)
     self.engines = [engine.StepEngine(r.graphs, params, num_steps=num_steps, c_in=c_in, c_out=c_out,
                                       device=device, precision=precision) for r in self.ranks]
     self.exchangers = {

@@ -12,6 +12,11 @@ Inputs, statistics and parameters are seeded (synthetic.make_example / make_stat
 params.random_params): the test regenerates them and checks the stored digests.
 
     python tests/golden/make_golden_rollout40.py          # ~10 minutes on 8 cores
+
+`--config 0p25deg` writes tests/golden/rollout3_0p25deg_rows.npz instead: the SAME stack at the headline
+size (0.25 deg / 37 levels / M6, BASELINE.json configs[1] geometry), 3 autoregressive steps (one full
+fp32 oracle step is ~2 minutes on the GPU box's 128 host cores; generated there by a round-3 session,
+see tests/test_rollout3_fullsize_gpu.py).
 """
 import hashlib
 import os
@@ -41,13 +46,28 @@ LAT = np.arange(-90, 90 + RES / 2, RES)
 LON = np.arange(0, 360, RES)
 
 
-def setup():
-  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
-  params = gparams.random_params(c_in, c_out, 512, GNN_STEPS, seed=SEEDS["params"])
-  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, num_target_steps=N_STEPS,
+class Config:
+  """One fixture = one (grid, task, number of autoregressive steps)."""
+
+  def __init__(self, name, res, mesh, task, n_steps, fixture):
+    self.name, self.res, self.mesh, self.task, self.n_steps, self.fixture = name, res, mesh, task, n_steps, fixture
+    self.lat = np.arange(-90, 90 + res / 2, res)
+    self.lon = np.arange(0, 360, res)
+    self.c_in = 2 * (5 + 6 * len(task.pressure_levels)) + 2 * 5 + 2 + 5
+    self.c_out = gc.num_output_channels(task)
+
+
+CONFIGS = {"1deg": Config("1deg", RES, MESH, gc.TASK_13, N_STEPS, "rollout40_1deg_rows.npz"),
+           "0p25deg": Config("0p25deg", 0.25, 6, gc.TASK, 3, "rollout3_0p25deg_rows.npz")}
+
+
+def setup(config="1deg"):
+  cfg = CONFIGS[config]
+  params = gparams.random_params(cfg.c_in, cfg.c_out, 512, GNN_STEPS, seed=SEEDS["params"])
+  inputs, template, forcings = synthetic.make_example(cfg.task, cfg.lat, cfg.lon, num_target_steps=cfg.n_steps,
                                                       seed=SEEDS["example"])
-  stats = synthetic.make_stats(gc.TASK_13)
-  rows = np.sort(np.random.default_rng(SEEDS["rows"]).choice(len(LAT) * len(LON), N_ROWS, replace=False))
+  stats = synthetic.make_stats(cfg.task)
+  rows = np.sort(np.random.default_rng(SEEDS["rows"]).choice(len(cfg.lat) * len(cfg.lon), N_ROWS, replace=False))
   return params, inputs, template, forcings, stats, rows
 
 
@@ -71,33 +91,42 @@ def stacked_rows(ds, template, s, rows):
 
 
 class TorchOraclePredictor(predictor_base.Predictor):
-  def __init__(self, params, graphs):
-    self.params, self.graphs = params, graphs
+  def __init__(self, params, graphs, n_lat=len(LAT), n_lon=len(LON)):
+    self.params, self.graphs, self.n_lat, self.n_lon = params, graphs, n_lat, n_lon
 
   def __call__(self, inputs, targets_template, forcings, **kw):
     x = xarray.concat([model_utils.dataset_to_stacked(inputs),
                        model_utils.dataset_to_stacked(forcings)], dim="channels")
     x = np.asarray(model_utils.lat_lon_to_leading_axes(x).data, np.float32)
     y = torch_cpu.forward(self.params, self.graphs, x.reshape((-1,) + x.shape[2:]), GNN_STEPS)
-    y = xarray.DataArray(y.reshape((len(LAT), len(LON)) + y.shape[1:]),
+    y = xarray.DataArray(y.reshape((self.n_lat, self.n_lon) + y.shape[1:]),
                          dims=("lat", "lon", "batch", "channels"))
     return model_utils.stacked_to_dataset(model_utils.restore_leading_axes(y).variable, targets_template)
 
 
-def main():
-  params, inputs, template, forcings, (mean, std, dstd), rows = setup()
-  graphs = ogc.build_graphs(LAT, LON, MESH)
+def main(config="1deg", out_dir=HERE):
+  cfg = CONFIGS[config]
+  params, inputs, template, forcings, (mean, std, dstd), rows = setup(config)
+  t0 = time.perf_counter()
+  graphs = ogc.build_graphs(cfg.lat, cfg.lon, cfg.mesh)
+  t_graphs = time.perf_counter() - t0
   torch_cpu.set_threads()
-  ref = normalization.InputsAndResiduals(TorchOraclePredictor(params, graphs), std, mean, dstd)
+  ref = normalization.InputsAndResiduals(TorchOraclePredictor(params, graphs, len(cfg.lat), len(cfg.lon)), std, mean, dstd)
   t0 = time.perf_counter()
   want = rollout.chunked_prediction(lambda rng, **kw: ref(**kw), None, inputs, template, forcings)
   dt = time.perf_counter() - t0
-  traj = np.stack([stacked_rows(want, template, s, rows) for s in range(N_STEPS)]).astype(np.float32)
-  np.savez_compressed(os.path.join(HERE, "rollout40_1deg_rows.npz"), rows=rows, traj=traj,
+  traj = np.stack([stacked_rows(want, template, s, rows) for s in range(cfg.n_steps)]).astype(np.float32)
+  os.makedirs(out_dir, exist_ok=True)
+  np.savez_compressed(os.path.join(out_dir, cfg.fixture), rows=rows, traj=traj,
                       inputs_sha256=np.array(digest(params, inputs, forcings)),
-                      config=np.array([RES, MESH, GNN_STEPS, N_STEPS]))
-  print(f"wrote rollout40_1deg_rows.npz: traj {traj.shape}, oracle {dt:.0f} s")
+                      config=np.array([cfg.res, cfg.mesh, GNN_STEPS, cfg.n_steps]))
+  print(f"wrote {cfg.fixture}: traj {traj.shape}, oracle graphs {t_graphs:.0f} s, oracle rollout {dt:.0f} s")
 
 
 if __name__ == "__main__":
-  main()
+  import argparse
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--config", default="1deg", choices=sorted(CONFIGS))
+  ap.add_argument("--out-dir", default=HERE)
+  a = ap.parse_args()
+  main(a.config, a.out_dir)
