@@ -17,6 +17,7 @@ OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_BF16_GEMM, PREC_BF16 = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16gemm": PREC_BF16_GEMM, "bf16": PREC_BF16}
 ROWS_F32 = 1                                      # GC_ROWS_F32 (gc_rowmlp_desc.flags)
+W2_NATURAL = 2                                    # GC_W2_NATURAL
 LAYOUT_CHUNKED, LAYOUT_HALF = 0, 2
 LATENT = 512
 TILE_ROWS = 64

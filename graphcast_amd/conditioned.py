@@ -66,6 +66,7 @@ class ConditionedEncoderDecoder(engine.StepEngine):
     import os
     self.half = (os.environ.get("GCAST_HALF", engine.DEFAULT_HALF) == "1") and self.prec == nat.PREC_F16X3
     self.scratch = None
+    self.onepass = False       # (its launches carry per-batch LayerNorm vectors through the two-pass kernels)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     self.c_grid, self.c_mesh, self.c_cond, self.c_out = c_grid, c_mesh, c_cond, c_out
     if c_out > 240:

@@ -1377,24 +1377,24 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlp_kernel");
 }
 
-bool g_h_attr_set[3] = {false, false, false};
+bool g_h_attr_set[3][4] = {};
 
-template <int MODE>
+template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = kHLdsFloats * sizeof(float);
-  if (!g_h_attr_set[MODE]) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16h_kernel<MODE>),
+  if (!g_h_attr_set[MODE][ONEPASS]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16h_kernel<MODE, ONEPASS>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
       return GC_ELAUNCH;
     }
-    g_h_attr_set[MODE] = true;
+    g_h_attr_set[MODE][ONEPASS] = true;
   }
   // persistent workgroups: two per CU on the 256 CUs of an MI355X, each walking tiles b, b + grid, ...
   const int tiles = (d.n_rows + kHRows - 1) / kHRows;
   const int grid = tiles < GC_SCRATCH_SLOTS ? tiles : GC_SCRATCH_SLOTS;
-  hipLaunchKernelGGL(rowmlp16h_kernel<MODE>, dim3(grid), dim3(256), lds, s, d);
+  hipLaunchKernelGGL((rowmlp16h_kernel<MODE, ONEPASS>), dim3(grid), dim3(256), lds, s, d);
   return check_launch("rowmlp16h_kernel");
 }
 
@@ -1497,7 +1497,7 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
     return fail(GC_EINVAL, "gc_rowmlp: unknown weight layout");
   if (d.layout == GC_LAYOUT_HALF) {
     if (d.prec != GC_PREC_F16X3) return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF is built for GC_PREC_F16X3 only");
-    if (d.mode == GC_MODE_MLP_LN && (!d.scratch || !aligned16(d.scratch)))
+    if (d.mode == GC_MODE_MLP_LN && !(d.flags & GC_W2_NATURAL) && (!d.scratch || !aligned16(d.scratch)))
       return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF + GC_MODE_MLP_LN needs a 16-byte aligned scratch");
   }
   if (d.n_chain != 0) {
@@ -1551,7 +1551,15 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
       } else if (!d.out && d.n_chain == 0) {
         return fail(GC_EINVAL, "gc_rowmlp MLP_LN: nothing to produce (no out, no seg, no chain)");
       }
-      if (d.layout == GC_LAYOUT_HALF) return launch_rowmlp_half<GC_MODE_MLP_LN>(d, s);
+      if (d.layout == GC_LAYOUT_HALF) {
+        if (d.flags & GC_W2_NATURAL) {        // the one-pass formulation of a launch without a layer-1 GEMM
+          if (d.k0 + d.k1 != 0 || !d.d || !d.g0 || d.n_chain != 0)
+            return fail(GC_EINVAL, "gc_rowmlp: GC_W2_NATURAL needs k0 + k1 == 0, d and g0, no chain");
+          return d.g1 ? launch_rowmlp_half<GC_MODE_MLP_LN, 3>(d, s) : launch_rowmlp_half<GC_MODE_MLP_LN, 2>(d, s);
+        }
+        return launch_rowmlp_half<GC_MODE_MLP_LN>(d, s);
+      }
+      if (d.flags & GC_W2_NATURAL) return fail(GC_EINVAL, "gc_rowmlp: GC_W2_NATURAL is a GC_LAYOUT_HALF feature");
       return launch_rowmlp<GC_MODE_MLP_LN>(d, s);
     case GC_MODE_MLP_OUT:
       if (!d.w2p || !d.b2 || d.n2 <= 0 || d.n2 > 240 || !d.out) return fail(GC_EINVAL, "gc_rowmlp MLP_OUT: needs w2p, b2, out, 0 < n2 <= 240");

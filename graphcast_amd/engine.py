@@ -98,6 +98,12 @@ class _Mlp:
     self.k_in = w1.shape[0]
     self.n_out = w2.shape[1]
     self._w1_raw, self._pack2, self._chained = w1, pack2, {}
+    # f16x3: W2 once more in the NATURAL K order, for the one-pass launches (GC_W2_NATURAL) of the
+    # edge updates that have no layer-1 GEMM (include/gcast.h); same scale as the chained image
+    self.w2_natural = None
+    if prec == nat.PREC_F16X3 and split is not None and len(split) == 3 and np2 == D:
+      sc = packing.choose_weight_scale(w2)
+      self.w2_natural = _PW(up(packing.pack_weight_split(w2, np_cols=D, chained=False, scale=sc).view(np.int16)), sc)
     # W1 either whole, or split into named row blocks of 512 (concat order)
     if split is None:
       self.w1 = pack1(w1)
@@ -164,6 +170,7 @@ class StepEngine:
     self.scratch = None
     # chained Linear layers + in-place grid input (only the half-N kernels have them); GCAST_FUSE=0
     # keeps one launch per reference layer group for A/B runs
+    self.onepass = os.environ.get("GCAST_ONEPASS", "1") == "1"     # (0: the two-pass launches everywhere, for A/B runs)
     self.fuse = self.half and (os.environ.get("GCAST_FUSE", "1") == "1" or self.prec == nat.PREC_BF16)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     # Spatially partitioned graphs (partition.plan): node tables that edges GATHER from carry a
@@ -203,7 +210,7 @@ class StepEngine:
   def _desc(self, mode, n_rows, *, a0=None, k0=0, lda0=None, a1=None, k1=0, lda1=None, w1p=None,
             d=None, g0=None, idx0=None, g1=None, idx1=None, b1=None, w2p=None, b2=None, n2=0,
             ln=None, res=None, out=None, ldo=None, out_ptr=None, edges: Optional[_Edges] = None,
-            agg=None, chain=(), rows_f32=False):
+            agg=None, chain=(), rows_f32=False, w2_natural=None):
     ds = nat.RowMlpDesc()
     ds.flags = nat.ROWS_F32 if (rows_f32 and self.prec == nat.PREC_BF16) else 0
     ds.mode, ds.n_rows, ds.prec = mode, n_rows, self.prec
@@ -230,6 +237,10 @@ class StepEngine:
     ds.b1 = nat.ptr(b1)
     ds.w2p, ds.b2, ds.n2 = nat.ptr(w2p), nat.ptr(b2), n2
     ds.w2_scale = w2p.scale if w2p is not None else 1.0
+    if (w2_natural is not None and self.onepass and self.half and self.prec == nat.PREC_F16X3
+        and mode == nat.MODE_MLP_LN and k0 + k1 == 0 and d is not None and g0 is not None and not chain):
+      # an edge update whose first layer was folded into addends: ONE pass (csrc/rowmlp_half.inc ONEPASS)
+      ds.w2p, ds.flags = w2_natural.data_ptr(), ds.flags | nat.W2_NATURAL
     if ln is not None:
       ds.ln_scale, ds.ln_offset = nat.ptr(ln[0]), nat.ptr(ln[1])
     ds.res, ds.ldres = nat.ptr(res), (res.shape[1] if res is not None else 0)
@@ -278,7 +289,7 @@ class StepEngine:
 
   def _mlp_ln(self, n_rows, mlp: _Mlp, **kw):
     return self._desc(nat.MODE_MLP_LN, n_rows, w2p=mlp.w2, b2=mlp.b2, n2=D,
-                      ln=(mlp.scale, mlp.offset), **kw)
+                      ln=(mlp.scale, mlp.offset), w2_natural=getattr(mlp, "w2_natural", None), **kw)
 
   # ---------------------------------------------------------------- build
   def _build(self, graphs, params, fold_only=False):

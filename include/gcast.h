@@ -94,6 +94,13 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
 
 /* gc_rowmlp_desc.flags */
 #define GC_ROWS_F32 1            /* GC_PREC_BF16: a0 / a1 are external fp32 rows in natural column order */
+#define GC_W2_NATURAL 2          /* GC_PREC_F16X3 + GC_LAYOUT_HALF + GC_MODE_MLP_LN launch WITHOUT a layer-1 GEMM
+                                  * (k0 + k1 == 0; d and g0 given, g1 optional, no chain): w2p is packed in the
+                                  * NATURAL K order and the launch runs in ONE pass -- every K chunk's hidden
+                                  * columns are formed on the fly from the same columns of the addend rows, the
+                                  * whole output row accumulates in registers, nothing is parked (no `scratch`).
+                                  * Same arithmetic as the two-pass launch up to the summation order inside an
+                                  * MFMA (csrc/rowmlp_half.inc, ONEPASS). */
 
 /* How w1p / w2p are packed, i.e. which tile formulation runs.
  *   GC_LAYOUT_CHUNKED  the layouts described above: 32-row K chunks staged through LDS, every wave

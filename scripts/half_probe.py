@@ -146,6 +146,14 @@ def main():
     d.seg, d.tile_flags, d.agg, d.partial = rcv3.data_ptr(), flags3.data_ptr(), agg3.data_ptr(), partial3.data_ptr()
     return d, n_e3, 2.0 * n_e3 * D * D
 
+  w2n = up(packing.pack_weight_split(w, chained=False, scale=sc).view(np.int16))
+
+  def dec_edge_onepass(layout):       # the same launch in the ONE-PASS formulation (GC_W2_NATURAL)
+    d, rows, flop = dec_edge(layout)
+    if layout == nat.LAYOUT_HALF:
+      d.w2p, d.flags = w2n.data_ptr(), nat.W2_NATURAL
+    return d, rows, flop
+
   def linear_grid(layout):
     d = desc(nat.MODE_LINEAR, n_g, layout)
     d.a0, d.lda0, d.k0, d.w1p = hg.data_ptr(), D, D, w1.data_ptr()
@@ -168,7 +176,8 @@ def main():
     d.out, d.ldo = yg.data_ptr(), 227
     return d, n_g, 2.0 * n_g * (D * D + D * 240)
 
-  shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, gemm_only_cached_rows=gemm_only_cached_rows, dec_edge=dec_edge, linear_grid=linear_grid,
+  shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, gemm_only_cached_rows=gemm_only_cached_rows, dec_edge=dec_edge,
+                dec_edge_onepass=dec_edge_onepass, linear_grid=linear_grid,
                 node_grid=node_grid, dec_out=dec_out)
   only = os.environ.get("PROBE_SHAPES")
   if only:

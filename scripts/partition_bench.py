@@ -53,7 +53,8 @@ def main():
   params = B.fast_params(c_in, c_out, gnn_steps)
   model = gc.GraphCast(cfg, task, params=params, device=device).init_from_coordinates(lat, lon)
   g = model.graph_arrays()
-  mine = partition.plan(g, model._grid_nodes_lon, model._mesh_nodes_lon, world)[rank]
+  mine = partition.plan(g, model._grid_nodes_lon, model._mesh_nodes_lon, world, grid_lat=model._grid_nodes_lat,
+                        mesh_lat=model._mesh_nodes_lat)[rank]
   step = partition.DistributedPartitionedStep(mine, params, num_steps=gnn_steps, c_in=c_in, c_out=c_out,
                                               device=device)
   x = torch.from_numpy(np.random.default_rng(0).standard_normal(

@@ -53,7 +53,8 @@ def main():
   ms_full = timed(lambda: model.forward_grid_node_features(x))
   t0 = time.perf_counter()
   step = partition.EmulatedPartitionedStep(g, params, model._grid_nodes_lon, model._mesh_nodes_lon,
-                                           args.parts, num_steps=gnn_steps, c_in=c_in, c_out=c_out)
+                                           args.parts, num_steps=gnn_steps, c_in=c_in, c_out=c_out,
+                                           grid_lat=model._grid_nodes_lat, mesh_lat=model._mesh_nodes_lat)
   build_s = time.perf_counter() - t0
   y = step(x)
   torch.cuda.synchronize()
@@ -62,7 +63,7 @@ def main():
   ranks = step.ranks
   rows = lambda f: [int(f(r)) for r in ranks]
   out = {
-      "config": f"GraphCast {args.config}, {args.parts} longitude bands, receiver-owned edges",
+      "config": f"GraphCast {args.config}, {args.parts} parts ({'octants' if args.parts == 8 else 'hemispheres / quadrants' if args.parts in (2, 4) else 'longitude bands'}), receiver-owned edges",
       "rel_diff_vs_unpartitioned": rel, "exchanges_per_step": step.exchanges_per_call,
       "ms_unpartitioned_step": ms_full, "ms_sum_of_all_ranks_emulated_on_one_gpu": ms_part,
       "ms_per_rank_if_perfectly_parallel": ms_part / args.parts,

@@ -27,7 +27,8 @@ def main():
   c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
   params = oparams.init_params(c_in, c_out, 512, steps, seed=1, nontrivial=True)
   model = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(lat, lon)
-  me = partition.plan(model.graph_arrays(), model._grid_nodes_lon, model._mesh_nodes_lon, world)[rank]
+  me = partition.plan(model.graph_arrays(), model._grid_nodes_lon, model._mesh_nodes_lon, world,
+                      grid_lat=model._grid_nodes_lat, mesh_lat=model._mesh_nodes_lat)[rank]
   x = np.random.default_rng(0).standard_normal((len(lat) * len(lon), 2, c_in)).astype(np.float32)
   step = partition.DistributedPartitionedStep(me, params, num_steps=steps, c_in=c_in, c_out=c_out,
                                               device="cuda:0")

@@ -19,7 +19,9 @@ def main():
   lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
   g = ogc.build_graphs(lat, lon, mesh)
   glon = np.meshgrid(lon, lat)[0].reshape(-1)
-  me = partition.plan(g, glon, np.asarray(g["mesh_lon"]), world)[rank]
+  glat = np.meshgrid(lon, lat)[1].reshape(-1)
+  me = partition.plan(g, glon, np.asarray(g["mesh_lon"]), world, grid_lat=glat,
+                      mesh_lat=np.asarray(g["mesh_lat"]))[rank]            # (2 ranks: hemispheres)
   rng = np.random.default_rng(0)                     # same global tables on every rank
   for name, key, n_glob, owned in (("g2m", "g2m", g["n_grid"], me.grid_owned),
                                    ("mesh", "mesh", g["n_mesh"], me.mesh_owned),

@@ -40,7 +40,8 @@ def test_partitioned_step_equals_full_step(setup, n_parts):
   m = setup["model"]
   step = partition.EmulatedPartitionedStep(
       m.graph_arrays(), setup["params"], m._grid_nodes_lon, m._mesh_nodes_lon, n_parts,
-      num_steps=setup["steps"], c_in=setup["c_in"], c_out=setup["c_out"])
+      num_steps=setup["steps"], c_in=setup["c_in"], c_out=setup["c_out"],
+      grid_lat=m._grid_nodes_lat, mesh_lat=m._mesh_nodes_lat)          # 2 / 8 parts: hemispheres / octants; 3: bands
   y = step(setup["x"])
   torch.cuda.synchronize()
   assert step.exchanges_per_call == 2 * (2 + setup["steps"])        # batch 2 x (enc + steps + dec)
@@ -60,7 +61,8 @@ def test_partitioned_step_against_oracle(setup):
   m = setup["model"]
   step = partition.EmulatedPartitionedStep(
       m.graph_arrays(), setup["params"], m._grid_nodes_lon, m._mesh_nodes_lon, 4,
-      num_steps=setup["steps"], c_in=setup["c_in"], c_out=setup["c_out"])
+      num_steps=setup["steps"], c_in=setup["c_in"], c_out=setup["c_out"],
+      grid_lat=m._grid_nodes_lat, mesh_lat=m._mesh_nodes_lat)          # quadrants
   got = step(setup["x"]).cpu().numpy().astype(np.float64)
   assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-5
 

@@ -309,6 +309,32 @@ def test_edge_block_with_segment_sum(dev, case):
   agg.fill_(float("nan"))
   pipeline()
   assert torch.equal(first, agg)
+  if not _HALF:
+    return
+  # ---- the ONE-PASS formulation of the same launch (GC_W2_NATURAL: no layer-1 GEMM, so every K chunk's
+  #      hidden columns are formed on the fly from the addend rows; W2 in the natural K order; no scratch),
+  #      with three addend sources and with two (the encoder edge update has no receiver term)
+  sc2 = packing.choose_weight_scale(p["w2"])
+  w2n_img = packing.pack_weight_split(p["w2"], chained=False, scale=sc2).view(np.int16).view(Image)
+  w2n_img.scale = sc2
+  w2n = up(w2n_img, dev)
+  for with_g1 in (True, False):
+    d.w2p, d.flags, d.scratch = w2n.data_ptr(), nat.W2_NATURAL, None
+    if not with_g1:
+      d.g1, d.idx1 = None, None
+    agg.fill_(float("nan"))
+    out.zero_()
+    pipeline()
+    extra1 = dd.astype(np.float64) + gs[np.maximum(pk.senders, 0)] + (gr[np.maximum(pk.receivers, 0)] if with_g1 else 0.0)
+    e1 = _mlp_ln_want(p, extra1)
+    assert_close(out.cpu().numpy()[ok], e1[ok], f"one-pass edge rows {case} g1={with_g1}")
+    want1 = ognn.segment_sum(e1[ok], pk.receivers[ok], n_recv)
+    got1 = agg.cpu().numpy()
+    assert np.isfinite(got1).all()
+    assert np.linalg.norm(got1 - want1) <= 2 * REL_RMSE_TOL[_PREC] * np.linalg.norm(want1)
+    again = agg.clone()
+    pipeline()
+    assert torch.equal(again, agg)
 
 
 @pytest.mark.parametrize("n_rows,n2,batch", [(64, 227, 1), (500, 83, 2), (70, 240, 1)])
