@@ -122,8 +122,49 @@ def library_path(variant=None):
   return os.path.join(_CSRC, VARIANTS[variant][0])
 
 
+# Register budget of the kernels that are built to run TWO workgroups per CU (csrc/rowmlp_half.inc,
+# rowmlp_bf16.inc): hipcc's -Rpass-analysis=kernel-resource-usage remarks are parsed at build time and the
+# build FAILS when one of them drops to one wave per SIMD or spills more than this many bytes per lane
+# (a regression there costs the second workgroup or puts scratch traffic into the GEMM loops without
+# changing any result, so no test would notice).  Today: LINEAR 0, MLP_OUT 0, one-pass 0, the two-pass
+# MLP_LN 116 bytes (56 spilled VGPRs + 60 SGPRs parked in VGPR lanes, all outside the MFMA streams:
+# address and descriptor values around the prologue / epilogue), the bf16 tier 260.
+RESOURCE_LIMITS = {"rowmlp16h_kernel": dict(scratch=160, occupancy=2), "rowmlpbf_kernel": dict(scratch=320, occupancy=2)}
+
+
+def check_resources(remarks, limits=None):
+  """Parses hipcc's kernel-resource-usage remarks -> {kernel symbol: {scratch, occupancy, vgprs, ...}}; raises if
+  a kernel named in `limits` exceeds its scratch budget or falls below its occupancy."""
+  import re
+  limits = RESOURCE_LIMITS if limits is None else limits
+  usage, cur = {}, None
+  for line in remarks.splitlines():
+    m = re.search(r"remark: Function Name: (\S+)", line)
+    if m:
+      cur = usage.setdefault(m.group(1), {})
+      continue
+    if cur is None:
+      continue
+    for key, pat in (("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"),
+                     ("vgprs", r" VGPRs: (\d+)"), ("vgpr_spill", r"VGPRs Spill: (\d+)"), ("sgpr_spill", r"SGPRs Spill: (\d+)")):
+      m = re.search(pat, line)
+      if m:
+        cur[key] = int(m.group(1))
+  bad = []
+  for sym, u in usage.items():
+    for name, lim in limits.items():
+      if name in sym and u:
+        if u.get("scratch", 0) > lim["scratch"] or u.get("occupancy", lim["occupancy"]) < lim["occupancy"]:
+          bad.append(f"{sym}: scratch {u.get('scratch')} B/lane (limit {lim['scratch']}), occupancy "
+                     f"{u.get('occupancy')} (needs {lim['occupancy']})")
+  if bad:
+    raise RuntimeError("register budget of a two-workgroups-per-CU kernel regressed:\n  " + "\n  ".join(bad))
+  return usage
+
+
 def build(force=False, verbose=False):
-  """Compiles csrc/gcast.hip for gfx950 with hipcc (all build variants)."""
+  """Compiles csrc/gcast.hip for gfx950 with hipcc (all build variants) and checks the register budget of
+  the hot kernels from the compiler's resource-usage remarks."""
   src = os.path.join(_CSRC, "gcast.hip")
   hdr = os.path.join(_INCLUDE, "gcast.h")
   deps = [src, hdr] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".inc")]
@@ -133,10 +174,22 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
       continue
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm",
-           define, "-I", _INCLUDE, "-shared", "-fPIC", src, "-o", out]
+           "-Rpass-analysis=kernel-resource-usage", define, "-I", _INCLUDE, "-shared", "-fPIC", src, "-o", out]
     if verbose:
       print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if res.returncode != 0:
+      sys.stderr.write(res.stderr)
+      raise subprocess.CalledProcessError(res.returncode, cmd)
+    try:
+      usage = check_resources(res.stderr)
+    except RuntimeError:
+      os.remove(out)
+      raise
+    if verbose:
+      for sym, u in sorted(usage.items()):
+        if any(k in sym for k in RESOURCE_LIMITS):
+          print(f"  {sym}: {u}", file=sys.stderr)
 
 
 _lib = None

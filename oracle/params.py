@@ -122,3 +122,38 @@ def digest(params):
 
 def count(params):
   return sum(int(np.prod(a.shape)) for m in params.values() for a in m.values())
+
+
+def init_deep_gnn_params(latent, steps, node_sets, edge_sets, pre_gather_matmul=False, name="DeepGNN", seed=1):
+  """Seeded float32 parameters of the WN2 ``DeepGNN`` processor (reference utils/deep_gnn.py:45-400 with
+  ``dense.DenseLayer`` MLPs of one hidden layer + "layer_norm"): haiku names as the reference creates
+  them (``hk.transparent`` builder, ``hk.name_like("__call__")`` constructors -- executed on the
+  stand-ins by tests/golden/make_golden_deepgnn.py, which asserts that this tree is exactly what the
+  reference asks for):
+    "<name>/processor_edges_<i>_<edge set>/mlp/linear_0|1", ".../normalization/layer_norm",
+    "<name>/processor_nodes_<i>_<node set>/...";  with ``pre_gather_matmul``: linear_0 of an edge MLP is
+    a bias only and its matrix lives in "<name>/processor_edges_<i>_{edge,sender,receiver}_<edge set>" {"w"}.
+  node_sets: {name: number of edge sets it receives from}; edge_sets: names.  Non-trivial biases / LayerNorm."""
+  rng = np.random.default_rng(seed)
+  d = latent
+  tn = lambda fan_in, shape: (stats.truncnorm.ppf(rng.random(shape), -2.0, 2.0) / np.sqrt(fan_in)).astype(np.float32)
+  vec = lambda scale, mean=0.0: (mean + scale * rng.standard_normal(d)).astype(np.float32)
+  params = {}
+
+  def dense(stem, fan_in, first_matrix=True):
+    if first_matrix:
+      params[f"{stem}/mlp/linear_0"] = {"w": tn(fan_in, (fan_in, d)), "b": vec(0.1)}
+    else:
+      params[f"{stem}/mlp/linear_0"] = {"b": vec(0.1)}
+    params[f"{stem}/mlp/linear_1"] = {"w": tn(d, (d, d)), "b": vec(0.1)}
+    params[f"{stem}/normalization/layer_norm"] = {"scale": vec(0.1, 1.0), "offset": vec(0.1)}
+
+  for i in range(steps):
+    for e in edge_sets:
+      if pre_gather_matmul:
+        for part in ("sender", "receiver", "edge"):
+          params[f"{name}/processor_edges_{i}_{part}_{e}"] = {"w": tn(3 * d, (d, d))}
+      dense(f"{name}/processor_edges_{i}_{e}", 3 * d, first_matrix=not pre_gather_matmul)
+    for n, n_recv in node_sets.items():
+      dense(f"{name}/processor_nodes_{i}_{n}", (1 + n_recv) * d)
+  return params

@@ -10,7 +10,8 @@ Published behaviour restated here:
   * hk.nets.MLP: Linear layers named linear_<i> created in __init__, activation
     between layers, activate_final=False;
   * hk.LayerNorm(axis, create_scale, create_offset, eps=1e-5): biased variance,
-    (x - mean) * rsqrt(var + eps) * scale + offset.
+    (x - mean) * rsqrt(var + eps) * scale + offset;
+  * hk.name_like / hk.transparent (naming scopes of utils/dense.py and utils/deep_gnn.py), hk.Bias.
 Parameters live in a {module_name: {param_name: array}} dict installed with
 `haiku.running(params, init_rng=None)`; with `init_rng` missing leaves are created
 (that is how make_golden.py learns the reference's parameter tree).
@@ -39,9 +40,13 @@ def running(params, init_rng=None, dtype=np.float64):
 
 
 def _wrap_method(name, fn):
+  if getattr(fn, "_hk_transparent", False):      # hk.transparent: no scope of its own
+    return fn
+  scope_name = getattr(fn, "_hk_name_like", name)     # hk.name_like: scoped as if it were that method
+
   @functools.wraps(fn)
   def wrapped(self, *a, **k):
-    _frames.append((self, name))
+    _frames.append((self, scope_name))
     try:
       return fn(self, *a, **k)
     finally:
@@ -187,8 +192,32 @@ class initializers:  # noqa: N801
 
 
 def name_like(method_name):
-  """hk.name_like: only decorates methods of modules that are imported but never run here."""
-  return lambda f: f
+  """hk.name_like(m): modules / parameters created in the decorated method are named as if they were
+  created in method `m` (utils/dense.py decorates every __init__ with name_like("__call__"): no "~"
+  path segment for sub-modules built in constructors)."""
+  def deco(f):
+    f._hk_name_like = method_name
+    return f
+  return deco
+
+
+def transparent(f):
+  """hk.transparent: the decorated method opens no naming scope -- what it creates is named in the scope
+  it is called from (utils/deep_gnn.py:185 `_networks_builder`)."""
+  f._hk_transparent = True
+  return f
+
+
+class Bias(Module):
+  """hk.Bias(bias_dims=[-1]): y = x + b, b [x.shape[-1]] (zeros by default)."""
+
+  def __init__(self, bias_dims=None, b_init=None, name=None):
+    super().__init__(name=name)
+    if bias_dims not in (None, [-1], (-1,)):
+      raise NotImplementedError("stand-in: bias over the last axis only")
+
+  def __call__(self, x):
+    return x + get_parameter("b", (x.shape[-1],), init=_constant(0.0))
 
 
 def remat(f, *a, **k):

@@ -79,3 +79,23 @@ def test_header_is_plain_c_and_the_c_host_example_links():
     subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), src,
                     "-L", os.path.join(root, "graphcast_amd", "csrc"), "-lgcast_hip", "-L", rocm_lib, "-lamdhip64",
                     "-lm", "-o", os.path.join(tmp, "plan_host")], check=True)
+
+
+def test_build_checks_the_register_budget_of_the_hot_kernels():
+  """_native.build() parses hipcc's kernel-resource-usage remarks and refuses a library whose two-workgroups-per-CU
+  kernels lost their occupancy or spill beyond their budget (nothing caught such a regression)."""
+  remark = ("x.inc:1:1: remark: Function Name: _ZN12_GLOBAL__N_116rowmlp16h_kernelILi1ELi0EEEv14gc_rowmlp_desc [-R]\n"
+            "x.inc:1:1: remark:     VGPRs: 256 [-R]\n"
+            "x.inc:1:1: remark:     ScratchSize [bytes/lane]: {scratch} [-R]\n"
+            "x.inc:1:1: remark:     Occupancy [waves/SIMD]: {occ} [-R]\n"
+            "x.inc:1:1: remark:     SGPRs Spill: 60 [-R]\n"
+            "x.inc:1:1: remark:     VGPRs Spill: 56 [-R]\n"
+            "x.inc:1:1: remark: Function Name: some_other_kernel [-R]\n"
+            "x.inc:1:1: remark:     ScratchSize [bytes/lane]: 4000 [-R]\n")
+  usage = nat.check_resources(remark.format(scratch=116, occ=2))
+  sym = "_ZN12_GLOBAL__N_116rowmlp16h_kernelILi1ELi0EEEv14gc_rowmlp_desc"
+  assert usage[sym] == dict(vgprs=256, scratch=116, occupancy=2, sgpr_spill=60, vgpr_spill=56)
+  with pytest.raises(RuntimeError, match="register budget"):
+    nat.check_resources(remark.format(scratch=348, occ=2))
+  with pytest.raises(RuntimeError, match="occupancy 1"):
+    nat.check_resources(remark.format(scratch=0, occ=1))
