@@ -25,7 +25,7 @@ def rowmlp_values(root, kernel_sub):
   for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f, newline="") as fh:
       for r in csv.DictReader(fh):
-        if kernel_sub in r["Kernel_Name"] and "<0>" not in r["Kernel_Name"]:
+        if kernel_sub in r["Kernel_Name"] and "<0" not in r["Kernel_Name"]:
           rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
   rows.sort()
   return [v for _, v in rows]
