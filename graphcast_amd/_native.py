@@ -13,7 +13,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
-OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP = 0, 1, 2, 3
+OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP, OP_ADD = 0, 1, 2, 3, 4
 PREC_F32, PREC_F16X3, PREC_BF16_GEMM, PREC_BF16 = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16gemm": PREC_BF16_GEMM, "bf16": PREC_BF16}
 ROWS_F32 = 1                                      # GC_ROWS_F32 (gc_rowmlp_desc.flags)
@@ -108,7 +108,7 @@ class AdvanceDesc(ctypes.Structure):
 
 
 EXPORTS = ("gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_plan_destroy",
-           "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_prep_grid_input", "gc_prep_grid_tail",
+           "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_add_rows", "gc_prep_grid_input", "gc_prep_grid_tail",
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
 
@@ -213,6 +213,8 @@ def lib():
     l.gc_seg_fixup_bf16.argtypes = [ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_void_p]
     l.gc_zero_rows_bf16.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_void_p]
     l.gc_seg_fixup_bf16.restype = l.gc_zero_rows_bf16.restype = ctypes.c_int
+    l.gc_add_rows.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_void_p]
+    l.gc_add_rows.restype = ctypes.c_int
     l.gc_prep_grid_input.argtypes = [ctypes.c_int] * 4 + [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp,
                                                           ctypes.c_void_p]
     l.gc_prep_grid_tail.argtypes = [ctypes.c_int] * 5 + [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp, ctypes.c_void_p]
@@ -222,7 +224,7 @@ def lib():
     l.gc_run_program.argtypes = [ctypes.POINTER(Op), ctypes.c_int, ctypes.c_void_p]
     l.gc_time_program.argtypes = [ctypes.POINTER(Op), ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
-    for name in ("gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_prep_grid_input",
+    for name in ("gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_add_rows", "gc_prep_grid_input",
                  "gc_run_program", "gc_time_program"):
       getattr(l, name).restype = ctypes.c_int
     l.gc_plan_create.argtypes = [ctypes.POINTER(ModelDesc), ctypes.POINTER(TensorDesc), ctypes.c_int,

@@ -1286,6 +1286,18 @@ __global__ void zero_rows_kernel(int n, const int* __restrict__ rows, float* __r
   *reinterpret_cast<f4*>(agg + (size_t)rows[e] * kD + threadIdx.x * 4) = f4{0.f, 0.f, 0.f, 0.f};
 }
 
+// dst[rows[i], :] += src[rows[i], :]: the aggregate of the halo-sender edges of a partitioned edge update joins
+// the aggregate of the sender-local ones (partition.py: the exchange runs under the local launch).
+__global__ void add_rows_kernel(int n, const int* __restrict__ rows, const float* __restrict__ src,
+                                float* __restrict__ dst) {
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  const size_t o = (size_t)rows[e] * kD + 4 * threadIdx.x;
+  f4 a = *reinterpret_cast<const f4*>(dst + o);
+  a += *reinterpret_cast<const f4*>(src + o);
+  *reinterpret_cast<f4*>(dst + o) = a;
+}
+
 __global__ void prep_grid_input_kernel(int n_rows, int batch, int b, int c_in, int c0,
                                        const float* __restrict__ x, int n_struct,
                                        const float* __restrict__ node_struct, int kp,
@@ -1607,6 +1619,14 @@ int gc_zero_rows(int n, const int* rows, float* agg, void* stream) {
   return check_launch("zero_rows_kernel");
 }
 
+int gc_add_rows(int n, const int* rows, const float* src, float* dst, void* stream) {
+  if (n < 0) return fail(GC_EINVAL, "gc_add_rows: negative count");
+  if (n == 0) return 0;
+  if (!rows || !src || !dst) return fail(GC_EINVAL, "gc_add_rows: null pointer");
+  hipLaunchKernelGGL(add_rows_kernel, dim3(n), dim3(kD / 4), 0, static_cast<hipStream_t>(stream), n, rows, src, dst);
+  return check_launch("add_rows_kernel");
+}
+
 int gc_prep_grid_input(int n_rows, int batch, int b, int c_in, const float* x, int n_struct,
                        const float* node_struct, int kp, float* xin, void* stream) {
   if (n_rows <= 0 || batch <= 0 || b < 0 || b >= batch || c_in <= 0 || n_struct < 0 ||
@@ -1659,6 +1679,8 @@ static int run_op(const gc_op& op, void* stream) {
     case GC_OP_ZERO:
       if (op.mlp.prec == GC_PREC_BF16) return gc_zero_rows_bf16(op.n, op.i0, op.dst, stream);
       return gc_zero_rows(op.n, op.i0, op.dst, stream);
+    case GC_OP_ADD:
+      return gc_add_rows(op.n, op.i0, op.src, op.dst, stream);
     case GC_OP_PREP:
       if (op.c0 > 0)
         return gc_prep_grid_tail(op.n, op.batch, op.b, op.c_in, op.c0, op.x, op.n_struct, op.node_struct, op.kp,

@@ -121,6 +121,14 @@ class _Mlp:
       self.offset = up(vec(np.asarray(params[f"{stem}_layer_norm"]["offset"], dtype=np.float32)))
 
 
+class _HaloPart:
+  """The halo-sender edges of one edge set of a partitioned graph (see StepEngine._build: split): packed edges,
+  folded first-layer term `d`, embedded latents `e0` / latent buffer `lat` (multi-mesh), receiver rows."""
+
+  def __init__(self, e, d, rows, e0=None):
+    self.e, self.d, self.rows, self.e0, self.lat = e, d, rows, e0, None
+
+
 class _Edges:
   """Device copy of a packed edge set."""
 
@@ -265,7 +273,7 @@ class StepEngine:
     op.kind, op.tag, op.mlp = nat.OP_ROWMLP, TAGS[tag], desc
     return op
 
-  def _ops_after_segsum(self, edges: _Edges, agg):
+  def _ops_after_segsum(self, edges: _Edges, agg, zero=True):
     ops = []
     if edges.fix is not None:
       op = nat.Op()
@@ -274,13 +282,23 @@ class StepEngine:
       op.i0, op.i1, op.i2 = (nat.ptr(t) for t in edges.fix)
       op.src, op.dst = nat.ptr(edges.partial), nat.ptr(agg)
       ops.append(op)
-    if edges.empty is not None:
+    if zero and edges.empty is not None:
       op = nat.Op()
       op.mlp.prec = self.prec
       op.kind, op.tag, op.n = nat.OP_ZERO, TAGS["fixup"], edges.empty.numel()
       op.i0, op.dst = nat.ptr(edges.empty), nat.ptr(agg)
       ops.append(op)
     return ops
+
+  def _halo_ops(self, name, tag, desc, agg, agg2):
+    """The second launch of a split edge update (`desc`: its descriptor, aggregating into `agg2`) + its fix-ups
+    + the join of its aggregate rows into `agg`."""
+    h = self.halo[name]
+    ops = [self._op_mlp(tag, desc)] + self._ops_after_segsum(h.e, agg2, zero=False)
+    op = nat.Op()
+    op.kind, op.tag, op.n = nat.OP_ADD, TAGS["fixup"], h.rows.numel()
+    op.i0, op.src, op.dst = nat.ptr(h.rows), nat.ptr(agg2), nat.ptr(agg)
+    return ops + [op]
 
   def _run(self, ops):
     arr = (nat.Op * len(ops))(*ops)
@@ -321,12 +339,6 @@ class StepEngine:
     self._keep += [self.m_enc_grid, self.m_g2m_edge, self.m_g2m_mesh, self.m_g2m_grid,
                    self.m_proc_edge, self.m_proc_node, self.m_m2g_edge, self.m_m2g_grid, self.m_out]
 
-    self.e_g2m = _Edges(packing.pack_edges(graphs["g2m"]["senders"], graphs["g2m"]["receivers"],
-                                           self.n_mesh), dev)
-    self.e_mesh = _Edges(packing.pack_edges(graphs["mesh"]["senders"], graphs["mesh"]["receivers"],
-                                            self.n_mesh), dev)
-    self.e_m2g = _Edges(packing.pack_edges(graphs["m2g"]["senders"], graphs["m2g"]["receivers"],
-                                           self.n_grid), dev)
     self.grid_struct = self._up(graphs["grid_node_feat"])
 
     # ---- load-time constant folding, on the device --------------------------
@@ -351,27 +363,67 @@ class StepEngine:
           nat.MODE_LINEAR, n_rows, a0=rows_in, k0=D, w1p=wp, out=out, **kw))])
       return out
 
+    # Spatially partitioned graphs: an edge set whose sender table carries a halo suffix is run as TWO
+    # launches -- the edges whose sender row this rank owns (the halo exchange runs under that launch) and
+    # the edges whose sender row arrives with the exchange; the second launch's aggregate rows are added
+    # to the first's (gc_add_rows).  OPT-IN (GCAST_OVERLAP=1): measured on the 0.25 deg graphs at 8-way
+    # (profiles/r03_s9_*), the 18 extra small launches + joins cost 1.6 ms per rank -- about what 18 exchanges of
+    # 0.86 MB cost over xGMI -- so the default stays one launch behind a blocking exchange.
+    overlap = os.environ.get("GCAST_OVERLAP", "0") == "1"
+
+    def split(g, n_owned):
+      snd = np.asarray(g["senders"])
+      halo = snd >= n_owned
+      if not overlap or not halo.any() or halo.all():
+        return g, None
+      pick = lambda m: dict(senders=snd[m], receivers=np.asarray(g["receivers"])[m], feat=np.asarray(g["feat"])[m])
+      return pick(~halo), pick(halo)
+
+    def recv_rows(edges: _Edges):
+      r = np.unique(edges.pk.receivers[edges.pk.receivers >= 0]).astype(np.int32)
+      return torch.from_numpy(r).to(dev)
+
     mesh_in = np.zeros((nm, self.kp), dtype=np.float32)
     mesh_in[:, self.c_in:self.c_in + self.n_struct] = graphs["mesh_node_feat"]
     self.h_mesh0 = embed(m_enc_mesh, torch.from_numpy(mesh_in).to(dev))            # [N_m, 512]
-    # grid2mesh edge first layer: e0.We + b1 + (h_mesh0.Wr)[receivers]   (per packed edge)
-    e0 = embed(m_enc_e_g2m, edge_feat_rows(self.e_g2m, graphs["g2m"]["feat"]))
     pre_r = linear(self.h_mesh0, self.m_g2m_edge.w1["r"])
-    self.d_g2m = linear(e0, self.m_g2m_edge.w1["e"], b1=self.m_g2m_edge.b1, g1=pre_r,
-                        idx1=self.e_g2m.rcv)
-    del e0, pre_r
+
+    def fold_g2m(gd):       # grid2mesh edge first layer: e0.We + b1 + (h_mesh0.Wr)[receivers]   (per packed edge)
+      e = _Edges(packing.pack_edges(gd["senders"], gd["receivers"], nm), dev)
+      e0 = embed(m_enc_e_g2m, edge_feat_rows(e, gd["feat"]))
+      return e, linear(e0, self.m_g2m_edge.w1["e"], b1=self.m_g2m_edge.b1, g1=pre_r, idx1=e.rcv)
+
+    def fold_mesh(gd):      # multi-mesh: embedded edges (kept: residual of step 0) and step-0 first-layer edge term
+      e = _Edges(packing.pack_edges(gd["senders"], gd["receivers"], nm), dev)
+      e0 = embed(m_enc_e_mesh, edge_feat_rows(e, gd["feat"]))
+      return e, e0, linear(e0, self.m_proc_edge[0].w1["e"], b1=self.m_proc_edge[0].b1)
+
+    def fold_m2g(gd):       # mesh2grid edge first layer: e0.We + b1
+      e = _Edges(packing.pack_edges(gd["senders"], gd["receivers"], ng), dev)
+      e0 = embed(m_enc_e_m2g, edge_feat_rows(e, gd["feat"]))
+      return e, linear(e0, self.m_m2g_edge.w1["e"], b1=self.m_m2g_edge.b1)
+
+    (g_g2m, h_g2m), (g_mesh, h_mesh), (g_m2g, h_m2g) = (split(graphs["g2m"], ng), split(graphs["mesh"], nm),
+                                                        split(graphs["m2g"], nm))
+    self.e_g2m, self.d_g2m = fold_g2m(g_g2m)
     # encoder mesh-node update first layer: h_mesh0.Wh + b1
     self.d_enc_mesh = linear(self.h_mesh0, self.m_g2m_mesh.w1["h"], b1=self.m_g2m_mesh.b1)
-    # multi-mesh: embedded edges (kept: residual of step 0) and step-0 first-layer edge term
-    self.e_mesh0 = embed(m_enc_e_mesh, edge_feat_rows(self.e_mesh, graphs["mesh"]["feat"]))
-    self.d_mesh0 = linear(self.e_mesh0, self.m_proc_edge[0].w1["e"], b1=self.m_proc_edge[0].b1)
-    # mesh2grid edge first layer: e0.We + b1
-    e0 = embed(m_enc_e_m2g, edge_feat_rows(self.e_m2g, graphs["m2g"]["feat"]))
-    self.d_m2g = linear(e0, self.m_m2g_edge.w1["e"], b1=self.m_m2g_edge.b1)
-    del e0
+    self.e_mesh, self.e_mesh0, self.d_mesh0 = fold_mesh(g_mesh)
+    self.e_m2g, self.d_m2g = fold_m2g(g_m2g)
+    self.halo = dict(g2m=None, mesh=None, m2g=None)
+    if h_g2m is not None:
+      e, d = fold_g2m(h_g2m)
+      self.halo["g2m"] = _HaloPart(e=e, d=d, rows=recv_rows(e))
+    if h_mesh is not None:
+      e, e0, d0 = fold_mesh(h_mesh)
+      self.halo["mesh"] = _HaloPart(e=e, e0=e0, d=d0, rows=recv_rows(e))
+    if h_m2g is not None:
+      e, d = fold_m2g(h_m2g)
+      self.halo["m2g"] = _HaloPart(e=e, d=d, rows=recv_rows(e))
+    del pre_r
     torch.cuda.synchronize(dev)
     self._keep += [self.h_mesh0, self.d_g2m, self.d_enc_mesh, self.e_mesh0, self.d_mesh0, self.d_m2g,
-                   self.e_g2m, self.e_mesh, self.e_m2g]
+                   self.e_g2m, self.e_mesh, self.e_m2g, self.halo]
 
     if fold_only:             # (Bf16StepEngine's helper: only the folded constants and packed edges are wanted)
       return
@@ -386,6 +438,12 @@ class StepEngine:
     self.pre_s_mesh = self._new(self.nm_tab)   # h_mesh.Ws (+ halo rows of remote senders)
     self.pre_r_mesh = self._new(nm)
     self.e_mesh_lat = self._new(self.e_mesh.n_rows)
+    if self.halo["mesh"] is not None:
+      self.halo["mesh"].lat = self._new(self.halo["mesh"].e.n_rows)
+    if self.halo["g2m"] is not None or self.halo["mesh"] is not None:
+      self.agg_mesh2 = self._new(nm)       # the halo-sender edges' aggregate rows, joined by gc_add_rows
+    if self.halo["m2g"] is not None:
+      self.agg_grid2 = self._new(ng)
 
   def _build_bf16(self, graphs, params):
     """GC_PREC_BF16 (the reference's Bfloat16Cast run, casting.py:31-65): bfloat16 weights and
@@ -418,6 +476,9 @@ class StepEngine:
                       device=dev, precision="f16x3", half=True, fold_only=True)
     pi = torch.from_numpy(packing.PI_PERM).to(dev)
     to_bf = lambda t: t.index_select(1, pi).to(torch.bfloat16).contiguous()
+    if any(v is not None for v in base.halo.values()):
+      raise NotImplementedError("the GC_PREC_BF16 tier does not run spatially partitioned graphs")
+    self.halo = dict(g2m=None, mesh=None, m2g=None)
     self.e_g2m, self.e_mesh, self.e_m2g = base.e_g2m, base.e_mesh, base.e_m2g
     self.grid_struct = base.grid_struct
     self.h_mesh0, self.d_g2m, self.d_enc_mesh = to_bf(base.h_mesh0), to_bf(base.d_g2m), to_bf(base.d_enc_mesh)
@@ -456,7 +517,7 @@ class StepEngine:
     """One launch per reference layer group (every formulation / precision)."""
     ng, nm = self.n_grid, self.n_mesh
     ops, x_slots, y_slots = [], [], []
-    cuts = []          # (index of the first op AFTER a halo exchange point, which table)
+    cuts = []          # (op index, table, "start" | "wait"): see segments()
     for b in range(batch):
       op = nat.Op()
       op.kind, op.tag, op.n = nat.OP_PREP, TAGS["prep"], ng
@@ -471,11 +532,7 @@ class StepEngine:
       m = self.m_g2m_edge
       ops.append(self._op_mlp("enc_pre", self._desc(
           nat.MODE_LINEAR, ng, a0=self.h_grid, k0=D, w1p=m.w1["s"], out=self.pre_grid)))
-      cuts.append((len(ops), "g2m"))
-      ops.append(self._op_mlp("enc_edge", self._mlp_ln(
-          self.e_g2m.n_rows, m, d=self.d_g2m, g0=self.pre_grid, idx0=self.e_g2m.snd,
-          edges=self.e_g2m, agg=self.agg_mesh)))
-      ops += self._ops_after_segsum(self.e_g2m, self.agg_mesh)
+      self._enc_edge_site(ops, cuts)
       m = self.m_g2m_mesh
       ops.append(self._op_mlp("enc_node_mesh", self._mlp_ln(
           nm, m, a0=self.agg_mesh, k0=D, w1p=m.w1["a"], d=self.d_enc_mesh, res=self.h_mesh0,
@@ -491,9 +548,7 @@ class StepEngine:
             nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=me.w1["s"], out=self.pre_s_mesh)))
         ops.append(self._op_mlp("proc_pre", self._desc(
             nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=me.w1["r"], out=self.pre_r_mesh)))
-        cuts.append((len(ops), "mesh"))
-        ops.append(self._op_mlp("proc_edge", self._proc_edge_desc(i)))
-        ops += self._ops_after_segsum(self.e_mesh, self.agg_mesh)
+        self._proc_edge_site(ops, cuts, i)
         ops.append(self._op_mlp("proc_node", self._mlp_ln(
             nm, mn, a0=self.h_mesh, k0=D, a1=self.agg_mesh, k1=D, w1p=mn.w1, b1=mn.b1,
             res=self.h_mesh, out=self.h_mesh)))
@@ -503,11 +558,7 @@ class StepEngine:
           nat.MODE_LINEAR, nm, a0=self.h_mesh, k0=D, w1p=m.w1["s"], out=self.pre_s_mesh)))
       ops.append(self._op_mlp("dec_pre", self._desc(
           nat.MODE_LINEAR, ng, a0=self.h_grid2, k0=D, w1p=m.w1["r"], out=self.pre_grid)))
-      cuts.append((len(ops), "m2g"))
-      ops.append(self._op_mlp("dec_edge", self._mlp_ln(
-          self.e_m2g.n_rows, m, d=self.d_m2g, g0=self.pre_s_mesh, idx0=self.e_m2g.snd,
-          g1=self.pre_grid, idx1=self.e_m2g.rcv, edges=self.e_m2g, agg=self.agg_grid)))
-      ops += self._ops_after_segsum(self.e_m2g, self.agg_grid)
+      self._dec_edge_site(ops, cuts)
       m = self.m_m2g_grid
       ops.append(self._op_mlp("dec_node", self._mlp_ln(
           ng, m, a0=self.h_grid2, k0=D, a1=self.agg_grid, k1=D, w1p=m.w1, b1=m.b1,
@@ -519,20 +570,57 @@ class StepEngine:
           n2=self.c_out, out_ptr=0, ldo=batch * self.c_out)))
     return ops, x_slots, y_slots, cuts
 
-  def _proc_edge_desc(self, i):
+  def _proc_edge_desc(self, i, part=None):
+    """Processor edge update of step i over the sender-local edges (part None) or the halo-sender ones."""
     me = self.m_proc_edge[i]
     last = i == self.num_steps - 1
-    common = dict(g0=self.pre_s_mesh, idx0=self.e_mesh.snd, g1=self.pre_r_mesh,
-                  idx1=self.e_mesh.rcv, edges=self.e_mesh, agg=self.agg_mesh)
+    e, e0, d0, lat, agg = ((self.e_mesh, self.e_mesh0, self.d_mesh0, self.e_mesh_lat, self.agg_mesh) if part is None
+                           else (part.e, part.e0, part.d, part.lat, self.agg_mesh2))
+    common = dict(g0=self.pre_s_mesh, idx0=e.snd, g1=self.pre_r_mesh, idx1=e.rcv, edges=e, agg=agg)
     if i == 0:
-      desc = self._mlp_ln(self.e_mesh.n_rows, me, d=self.d_mesh0, res=self.e_mesh0,
-                          out=None if last else self.e_mesh_lat, **common)
+      desc = self._mlp_ln(e.n_rows, me, d=d0, res=e0, out=None if last else lat, **common)
       if last:
         desc.res, desc.ldres = None, 0
       return desc
-    return self._mlp_ln(self.e_mesh.n_rows, me, a0=self.e_mesh_lat, k0=D, w1p=me.w1["e"],
-                        b1=me.b1, res=None if last else self.e_mesh_lat,
-                        out=None if last else self.e_mesh_lat, **common)
+    return self._mlp_ln(e.n_rows, me, a0=lat, k0=D, w1p=me.w1["e"], b1=me.b1, res=None if last else lat,
+                        out=None if last else lat, **common)
+
+  def _edge_site(self, ops, cuts, name, tag, main_desc, halo_desc, main_edges, agg, agg2):
+    """One edge update of the step: the launch over the sender-local edges (+ fix-ups), and -- partitioned graphs --
+    the launch over the halo-sender edges behind the exchange of table `name`.  `cuts` records where the exchange may
+    START (the producing launch is enqueued) and where it must have FINISHED."""
+    h = self.halo[name]
+    cuts.append((len(ops), name, "start"))
+    if h is None:
+      cuts.append((len(ops), name, "wait"))
+    ops.append(self._op_mlp(tag, main_desc()))
+    ops += self._ops_after_segsum(main_edges, agg)
+    if h is not None:
+      cuts.append((len(ops), name, "wait"))
+      ops += self._halo_ops(name, tag, halo_desc(h), agg, agg2)
+
+  def _enc_edge_site(self, ops, cuts):
+    m = self.m_g2m_edge
+    self._edge_site(
+        ops, cuts, "g2m", "enc_edge",
+        lambda: self._mlp_ln(self.e_g2m.n_rows, m, d=self.d_g2m, g0=self.pre_grid, idx0=self.e_g2m.snd,
+                             edges=self.e_g2m, agg=self.agg_mesh),
+        lambda h: self._mlp_ln(h.e.n_rows, m, d=h.d, g0=self.pre_grid, idx0=h.e.snd, edges=h.e, agg=self.agg_mesh2),
+        self.e_g2m, self.agg_mesh, getattr(self, "agg_mesh2", None))
+
+  def _proc_edge_site(self, ops, cuts, i):
+    self._edge_site(ops, cuts, "mesh", "proc_edge", lambda: self._proc_edge_desc(i),
+                    lambda h: self._proc_edge_desc(i, h), self.e_mesh, self.agg_mesh, getattr(self, "agg_mesh2", None))
+
+  def _dec_edge_site(self, ops, cuts):
+    m = self.m_m2g_edge
+    self._edge_site(
+        ops, cuts, "m2g", "dec_edge",
+        lambda: self._mlp_ln(self.e_m2g.n_rows, m, d=self.d_m2g, g0=self.pre_s_mesh, idx0=self.e_m2g.snd,
+                             g1=self.pre_grid, idx1=self.e_m2g.rcv, edges=self.e_m2g, agg=self.agg_grid),
+        lambda h: self._mlp_ln(h.e.n_rows, m, d=h.d, g0=self.pre_s_mesh, idx0=h.e.snd, g1=self.pre_grid,
+                               idx1=h.e.rcv, edges=h.e, agg=self.agg_grid2),
+        self.e_m2g, self.agg_grid, getattr(self, "agg_grid2", None))
 
   def _program_fused(self, batch):
     """GC_LAYOUT_HALF: the Linear layers that the reference applies to rows a launch has just
@@ -572,11 +660,7 @@ class StepEngine:
           ng, m, w1p=m.w1, b1=m.b1, out=self.h_grid, chain=[rows(self.m_g2m_edge, "s", self.pre_grid)],
           **src)))
       m = self.m_g2m_edge
-      cuts.append((len(ops), "g2m"))
-      ops.append(self._op_mlp("enc_edge", self._mlp_ln(
-          self.e_g2m.n_rows, m, d=self.d_g2m, g0=self.pre_grid, idx0=self.e_g2m.snd,
-          edges=self.e_g2m, agg=self.agg_mesh)))
-      ops += self._ops_after_segsum(self.e_g2m, self.agg_mesh)
+      self._enc_edge_site(ops, cuts)
       m = self.m_g2m_mesh
       first = self.m_proc_edge[0]
       ops.append(self._op_mlp("enc_node_mesh", self._mlp_ln(
@@ -591,9 +675,7 @@ class StepEngine:
       for i in range(self.num_steps):
         mn = self.m_proc_node[i]
         last = i == self.num_steps - 1
-        cuts.append((len(ops), "mesh"))
-        ops.append(self._op_mlp("proc_edge", self._proc_edge_desc(i)))
-        ops += self._ops_after_segsum(self.e_mesh, self.agg_mesh)
+        self._proc_edge_site(ops, cuts, i)
         if last:
           chain = [rows(self.m_m2g_edge, "s", self.pre_s_mesh)]
         else:
@@ -604,11 +686,7 @@ class StepEngine:
             res=self.h_mesh, out=self.h_mesh, chain=chain)))
       # ---- decoder (mesh2grid GNN) ----
       m = self.m_m2g_edge
-      cuts.append((len(ops), "m2g"))
-      ops.append(self._op_mlp("dec_edge", self._mlp_ln(
-          self.e_m2g.n_rows, m, d=self.d_m2g, g0=self.pre_s_mesh, idx0=self.e_m2g.snd,
-          g1=self.pre_grid, idx1=self.e_m2g.rcv, edges=self.e_m2g, agg=self.agg_grid)))
-      ops += self._ops_after_segsum(self.e_m2g, self.agg_grid)
+      self._dec_edge_site(ops, cuts)
       m, mo = self.m_m2g_grid, self.m_out
       y_slots.append((len(ops), "chain", 1))
       ops.append(self._op_mlp("dec_node", self._mlp_ln(
@@ -666,27 +744,27 @@ class StepEngine:
   def segments(self, x: torch.Tensor, y: Optional[torch.Tensor] = None):
     """The step as launch segments separated by halo exchange points (partition.py).
 
-    Returns ``(y, [(run, table_name), ...])``: call ``run()`` (enqueues the segment's launches on
-    the current stream), then exchange the halo suffix of ``self.halo_table(table_name)`` with
-    the other ranks (``table_name`` is None after the last segment).  18 exchange points per
-    batch element: 1 encoder, 1 per processor step, 1 decoder."""
+    Returns ``(y, [(run, actions), ...])``: call ``run()`` (enqueues the segment's launches on the current
+    stream), then perform ``actions`` in order -- ``("start", table)``: the launch that produced the owned
+    rows of ``self.halo_table(table)`` is enqueued, the exchange of its halo suffix may begin (on another
+    stream, behind an event); ``("wait", table)``: the next segment gathers from that suffix.  With split
+    edge updates (``self.halo[table]``) the sender-local launch lies between the two; otherwise they come
+    together.  18 exchanges per batch element: 1 encoder, 1 per processor step, 1 decoder."""
     bound, y = self.bind(x, y)
     # a private copy of the program: the closures below stay valid when the engine is bound to
     # other tensors before they have all run (interleaved partitioned steps, time_ops, ...)
     arr = (nat.Op * len(bound))()
     ctypes.memmove(arr, bound, ctypes.sizeof(bound))
     cuts = self._cuts[x.shape[1]]
-    bounds = [0] + [c for c, _ in cuts] + [len(arr)]
-    names = [n for _, n in cuts] + [None]
+    bounds = sorted({0, len(arr)} | {c for c, _, _ in cuts})
     segs = []
-    for k in range(len(bounds) - 1):
-      lo, hi = bounds[k], bounds[k + 1]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
       sub = ctypes.cast(ctypes.byref(arr, lo * ctypes.sizeof(nat.Op)), ctypes.POINTER(nat.Op))
 
       def run(sub=sub, n=hi - lo, keep=arr):        # (`keep`: the copy lives as long as the closure)
         with torch.cuda.device(self.dev):
           nat.check(self.lib.gc_run_program(sub, n, self._stream_ptr()), "gc_run_program")
-      segs.append((run, names[k]))
+      segs.append((run, [(kind, name) for c, name, kind in cuts if c == hi]))
     return y, segs
 
   def halo_table(self, name: str) -> torch.Tensor:

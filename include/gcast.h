@@ -221,6 +221,12 @@ int gc_seg_fixup(int n_entries, const int* recv, const int* t0, const int* t1,
  * "zeros for empty segments"). */
 int gc_zero_rows(int n, const int* rows, float* agg, void* stream);
 
+/* dst[rows[i], :] += src[rows[i], :] (fp32 rows of 512).  The spatially partitioned step runs an edge update
+ * as TWO launches -- edges whose sender row is local (under which the halo exchange runs) and edges whose
+ * sender row arrives with the exchange; this joins the second launch's aggregate rows into the first's
+ * (GC_OP_ADD: n, i0 = rows, src, dst).  Completes jraph.segment_sum (typed_graph_net.py:532-538) there. */
+int gc_add_rows(int n, const int* rows, const float* src, float* dst, void* stream);
+
 /* The same two for a GC_PREC_BF16 launch: `partial` fp32 rows in pi order, `agg` bfloat16 rows
  * (gc_run_program picks them for GC_OP_FIXUP / GC_OP_ZERO ops whose mlp.prec is GC_PREC_BF16). */
 int gc_seg_fixup_bf16(int n_entries, const int* recv, const int* t0, const int* t1, const float* partial,
@@ -276,7 +282,7 @@ int gc_advance_state(const gc_advance_desc* desc, void* stream);
 /* A recorded sequence of launches = one encode-process-decode step
  * (graphcast.py:306-323 between _inputs_to_grid_node_features and
  * _grid_node_outputs_to_prediction). */
-enum gc_op_kind { GC_OP_ROWMLP = 0, GC_OP_FIXUP = 1, GC_OP_ZERO = 2, GC_OP_PREP = 3 };
+enum gc_op_kind { GC_OP_ROWMLP = 0, GC_OP_FIXUP = 1, GC_OP_ZERO = 2, GC_OP_PREP = 3, GC_OP_ADD = 4 };
 
 typedef struct gc_op {
   int kind;                /* enum gc_op_kind */

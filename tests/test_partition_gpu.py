@@ -35,8 +35,12 @@ def setup():
               lat=lat, lon=lon, mesh_size=mesh_size)
 
 
+@pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("n_parts", [2, 3, 8])
-def test_partitioned_step_equals_full_step(setup, n_parts):
+def test_partitioned_step_equals_full_step(setup, n_parts, overlap, monkeypatch):
+  # overlap "1": every edge update split into its sender-local edges (the exchange runs on a second stream under
+  # that launch) and its halo-sender edges (launched behind the exchange, aggregate rows joined by gc_add_rows)
+  monkeypatch.setenv("GCAST_OVERLAP", overlap)
   m = setup["model"]
   step = partition.EmulatedPartitionedStep(
       m.graph_arrays(), setup["params"], m._grid_nodes_lon, m._mesh_nodes_lon, n_parts,
@@ -45,6 +49,7 @@ def test_partitioned_step_equals_full_step(setup, n_parts):
   y = step(setup["x"])
   torch.cuda.synchronize()
   assert step.exchanges_per_call == 2 * (2 + setup["steps"])        # batch 2 x (enc + steps + dec)
+  assert step.overlap == (overlap == "1")
   diff = (y - setup["y"]).double()
   rel = float(torch.linalg.vector_norm(diff) / torch.linalg.vector_norm(setup["y"].double()))
   print(f"{n_parts} parts: rel diff vs unpartitioned {rel:.2e}, "
