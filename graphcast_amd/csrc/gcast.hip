@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gcast.h"
@@ -1410,24 +1411,45 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlp16h_kernel");
 }
 
-bool g_bf_attr_set[2] = {false, false};
+bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};
 
-template <bool F32ROWS>
+// Rows per workgroup of a GC_PREC_BF16 launch: 64 (two workgroups per CU), or 128 (eight waves sharing
+// one weight stream, one workgroup per CU) for the big node-side launches -- no gather, no segment-sum,
+// at least kBfWideMinRows rows: measured 6-7 % faster there, 1-7 % slower on the edge updates
+// (profiles/r03_s12_*).  GCAST_BF16_ROWS=64|128 (read once) pins the choice for A/B runs.
+constexpr int kBfWideMinRows = 128 * 256 * 2;
+int bf16_rows_override() {
+  static const int v = [] {
+    const char* e = std::getenv("GCAST_BF16_ROWS");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+
+template <bool F32ROWS, int NW>
 int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
-  const size_t lds = kHLdsFloats * sizeof(float);
-  if (!g_bf_attr_set[F32ROWS]) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpbf_kernel<F32ROWS>),
+  const size_t lds = BfLds<NW>::kFloats * sizeof(float);
+  bool& attr_set = g_bf_attr_set[F32ROWS][NW / 8];
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpbf_kernel<F32ROWS, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
       return GC_ELAUNCH;
     }
-    g_bf_attr_set[F32ROWS] = true;
+    attr_set = true;
   }
-  const int tiles = (d.n_rows + kHRows - 1) / kHRows;
-  const int grid = tiles < GC_SCRATCH_SLOTS ? tiles : GC_SCRATCH_SLOTS;     // persistent: two workgroups per CU
-  hipLaunchKernelGGL(rowmlpbf_kernel<F32ROWS>, dim3(grid), dim3(256), lds, s, d);
+  const int tiles = (d.n_rows + 16 * NW - 1) / (16 * NW);
+  const int slots = GC_SCRATCH_SLOTS * 4 / NW;        // persistent: 8 / NW workgroups per CU
+  hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, d);
   return check_launch("rowmlpbf_kernel");
+}
+
+template <bool F32ROWS>
+int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
+  const int pin = bf16_rows_override();
+  const bool wide = pin == 128 || (pin != 64 && d.n_rows >= kBfWideMinRows && !d.seg && !d.g0 && !d.g1);
+  return wide ? launch_rowmlp_bf16<F32ROWS, 8>(d, s) : launch_rowmlp_bf16<F32ROWS, 4>(d, s);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }

@@ -176,7 +176,45 @@ def main():
     d.out, d.ldo = yg.data_ptr(), 227
     return d, n_g, 2.0 * n_g * (D * D + D * 240)
 
-  shapes = dict(proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, gemm_only_cached_rows=gemm_only_cached_rows, dec_edge=dec_edge,
+  # ---- the same shapes in the GC_PREC_BF16 tier (bfloat16 rows in pi order, bf16 weight images)
+  bf = lambda t: t.to(torch.bfloat16)
+  wb1 = up(packing.pack_weight_bf16(w, chained=True).view(np.int16))
+  wb1b = up(packing.pack_weight_bf16(np.concatenate([w, w]), chained=True).view(np.int16))
+  e_bf, tab_s_bf, tab_r_bf, hg_bf, d3_bf = bf(e), bf(tab_s), bf(tab_r), bf(hg), bf(d3)
+  og_bf, agg_bf, agg3_bf = torch.empty_like(hg_bf), torch.empty((n_mesh, D), dtype=torch.bfloat16, device=dev), torch.empty((n_gd, D), dtype=torch.bfloat16, device=dev)
+  eo_bf = torch.empty_like(e_bf)
+
+  def bdesc(n_rows):
+    d = nat.RowMlpDesc()
+    d.mode, d.n_rows, d.prec, d.layout, d.n2 = nat.MODE_MLP_LN, n_rows, nat.PREC_BF16, nat.LAYOUT_HALF, D
+    d.w2p, d.b2 = wb1.data_ptr(), vec.data_ptr()
+    d.ln_scale, d.ln_offset, d.b1 = one.data_ptr(), vec.data_ptr(), vec.data_ptr()
+    d.scratch = scratch.data_ptr()            # (only the trace build looks at it)
+    return d
+
+  def proc_edge_bf16(layout):
+    d = bdesc(n_e)
+    d.a0, d.lda0, d.k0, d.w1p = e_bf.data_ptr(), D, D, wb1.data_ptr()
+    d.g0, d.idx0, d.g1, d.idx1 = tab_s_bf.data_ptr(), snd.data_ptr(), tab_r_bf.data_ptr(), rcv.data_ptr()
+    d.res, d.ldres, d.out, d.ldo = e_bf.data_ptr(), D, eo_bf.data_ptr(), D
+    d.seg, d.tile_flags, d.agg, d.partial = rcv.data_ptr(), flags.data_ptr(), agg_bf.data_ptr(), partial.data_ptr()
+    return d, n_e, 2.0 * n_e * 2 * D * D
+
+  def dec_edge_bf16(layout):
+    d = bdesc(n_e3)
+    d.d, d.ldd = d3_bf.data_ptr(), D
+    d.g0, d.idx0, d.g1, d.idx1 = tab_s_bf.data_ptr(), snd3.data_ptr(), hg_bf.data_ptr(), rcv3.data_ptr()
+    d.seg, d.tile_flags, d.agg, d.partial = rcv3.data_ptr(), flags3.data_ptr(), agg3_bf.data_ptr(), partial3.data_ptr()
+    return d, n_e3, 2.0 * n_e3 * D * D
+
+  def node_grid_bf16(layout):
+    d = bdesc(n_g)
+    d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = hg_bf.data_ptr(), D, D, og_bf.data_ptr(), D, D
+    d.w1p = wb1b.data_ptr()
+    d.res, d.ldres, d.out, d.ldo = hg_bf.data_ptr(), D, og_bf.data_ptr(), D
+    return d, n_g, 2.0 * n_g * 3 * D * D
+
+  shapes = dict(proc_edge_bf16=proc_edge_bf16, dec_edge_bf16=dec_edge_bf16, node_grid_bf16=node_grid_bf16, proc_edge=proc_edge, gemm_only_mlp=gemm_only_mlp, gemm_only_cached_rows=gemm_only_cached_rows, dec_edge=dec_edge,
                 dec_edge_onepass=dec_edge_onepass, linear_grid=linear_grid,
                 node_grid=node_grid, dec_out=dec_out)
   only = os.environ.get("PROBE_SHAPES")
@@ -223,6 +261,8 @@ def main():
     row = {}
     for r in range(args.rounds):                      # ABAB...: every build once per round
       for tag, lib, layout in libs:
+        if name.endswith("_bf16") and layout != nat.LAYOUT_HALF:
+          continue                                   # (the tier exists in the persistent half-N form only)
         d, rows, flop = make(layout)
         ms = time_launch(lib, d, args.iters)
         row.setdefault(tag, []).append(ms)
@@ -242,6 +282,8 @@ def main():
                       "out_abs_max": float(ref_o.abs().max())}
     out = {"_check_vs_in_tree_half": check} if check else {}
     for tag, _, _ in libs:
+      if tag not in row:
+        continue
       ms = float(np.median(row[tag]))
       d, rows, flop = make(nat.LAYOUT_CHUNKED)
       out[tag] = {"ms": round(ms, 4), "ms_all": [round(v, 4) for v in row[tag]],
