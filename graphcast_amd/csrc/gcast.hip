@@ -1322,34 +1322,85 @@ __global__ void prep_grid_input_kernel(int n_rows, int batch, int b, int c_in, i
   }
 }
 
-// One wave per row; lanes stride over channels.  The per-channel tables (a few KiB) stay in
-// L1/K$; x / y rows are contiguous, so the gathered picks hit the lines the row read brought in.
-__global__ __launch_bounds__(256) void advance_state_kernel(const gc_advance_desc d) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= d.n_rows) return;
-  const float* x = d.x + (size_t)row * d.c_in;
-  const float* y = d.y + (size_t)row * d.c_out;
-  float* xn = d.x_next + (size_t)row * d.c_in;
-  for (int c = lane; c < d.c_in; c += 64) {
-    float v = 0.f;
-    const int sx = d.src_x[c], sy = d.src_y[c], sf = d.src_f[c];
-    if (sx >= 0) v = d.ax[c] * x[sx];
-    if (sy >= 0) v = fmaf(d.ay[c], y[sy], v);
-    if (sf >= 0) {
-      v += sf < d.n_forc ? d.f_cur[(size_t)row * d.n_forc + sf]
-                         : d.f_next[(size_t)row * d.n_forc + (sf - d.n_forc)];
-    }
-    xn[c] = v;
+// A block owns kAdvRows consecutive rows.  Their x and y rows are ONE contiguous range each: copied into
+// LDS with 16-byte loads (whole cache lines whatever the row length -- 474 floats = 1896 B), the next
+// state and the prediction are formed in LDS (thread t owns channels t, t + 256, ...: its table entries
+// are read once per block; the picks are 4-byte LDS reads) and leave as 16-byte stores of a contiguous
+// range again.  Same arithmetic, element for element, as the one-wave-per-row kernel of rounds 2-3
+// (2.33-2.43 ms per 0.25 deg step = 2.4 TB/s of useful bytes; this one 1.79 ms = 3.3 TB/s; two
+// direct-to-global variants of this round were no faster than the old one, profiles/r03_s18_* .. r03_s21_*).
+constexpr int kAdvRows = 8;        // 37 KiB of LDS at 474 -> 227 channels: four blocks per CU in different phases
+__device__ __forceinline__ void adv_copy(float* dst, const float* src, int n, bool vec, int t) {
+  if (vec) {
+    const int n4 = n >> 2;
+#pragma unroll 4
+    for (int e = t; e < n4; e += 256) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
+    for (int e = (n4 << 2) + t; e < n; e += 256) dst[e] = src[e];
+  } else {
+    for (int e = t; e < n; e += 256) dst[e] = src[e];
   }
-  if (d.pred) {
-    float* p = d.pred + (size_t)row * d.c_out;
-    for (int k = lane; k < d.c_out; k += 64) {
-      float v = fmaf(d.p_ay[k], y[k], d.p_b[k]);
-      const int sx = d.p_src_x[k];
-      if (sx >= 0) v = fmaf(d.p_ax[k], x[sx], v);
-      p[k] = v;
+}
+constexpr int kAdvMaxJ = 4;         // channels per thread: c_in, c_out <= 1024
+__global__ __launch_bounds__(256) void advance_state_kernel(const gc_advance_desc d, int vec) {
+  extern __shared__ __attribute__((aligned(16))) float adv_smem[];
+  const int t = threadIdx.x;
+  const int row0 = blockIdx.x * kAdvRows;
+  const int rows = d.n_rows - row0 < kAdvRows ? d.n_rows - row0 : kAdvRows;
+  const int xpad = (kAdvRows * d.c_in + 3) & ~3, ypad = (kAdvRows * d.c_out + 3) & ~3;
+  float* xs = adv_smem;                 // [rows, c_in]   the current state
+  float* xo = xs + xpad;                // [rows, c_in]   the next state
+  float* ys = xo + xpad;                // [rows, c_out]  the step's output, then (in place) the prediction
+  // this thread's table entries first: their round trip runs under the copies
+  int sx[kAdvMaxJ], sy[kAdvMaxJ], sf[kAdvMaxJ], psx[kAdvMaxJ];
+  float ax[kAdvMaxJ], ay[kAdvMaxJ], pax[kAdvMaxJ], pay[kAdvMaxJ], pb[kAdvMaxJ];
+#pragma unroll
+  for (int j = 0; j < kAdvMaxJ; ++j) {
+    const int c = t + 256 * j;
+    sx[j] = sy[j] = sf[j] = psx[j] = -1;
+    ax[j] = ay[j] = pax[j] = pay[j] = pb[j] = 0.f;
+    if (c < d.c_in) {
+      sx[j] = d.src_x[c]; sy[j] = d.src_y[c]; sf[j] = d.src_f[c];
+      ax[j] = d.ax[c]; ay[j] = d.ay[c];
     }
+    if (d.pred && c < d.c_out) {
+      psx[j] = d.p_src_x[c]; pax[j] = d.p_ax[c]; pay[j] = d.p_ay[c]; pb[j] = d.p_b[c];
+    }
+  }
+  adv_copy(xs, d.x + (size_t)row0 * d.c_in, rows * d.c_in, vec & 1, t);
+  adv_copy(ys, d.y + (size_t)row0 * d.c_out, rows * d.c_out, vec & 2, t);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kAdvMaxJ; ++j) {
+    const int c = t + 256 * j;
+    if (c < d.c_in) {
+      const float* pf = nullptr;
+      if (sf[j] >= 0)
+        pf = (sf[j] < d.n_forc ? d.f_cur + sf[j] : d.f_next + (sf[j] - d.n_forc)) + (size_t)row0 * d.n_forc;
+      for (int r = 0; r < rows; ++r) {
+        float v = 0.f;
+        if (sx[j] >= 0) v = ax[j] * xs[r * d.c_in + sx[j]];
+        if (sy[j] >= 0) v = fmaf(ay[j], ys[r * d.c_out + sy[j]], v);
+        if (pf) v += pf[(size_t)r * d.n_forc];
+        xo[r * d.c_in + c] = v;
+      }
+    }
+  }
+  __syncthreads();                      // every pick of y is done: the prediction may overwrite it
+  adv_copy(d.x_next + (size_t)row0 * d.c_in, xo, rows * d.c_in, vec & 4, t);
+  if (d.pred) {
+#pragma unroll
+    for (int j = 0; j < kAdvMaxJ; ++j) {
+      const int k = t + 256 * j;
+      if (k < d.c_out) {
+        for (int r = 0; r < rows; ++r) {
+          float v = fmaf(pay[j], ys[r * d.c_out + k], pb[j]);
+          if (psx[j] >= 0) v = fmaf(pax[j], xs[r * d.c_in + psx[j]], v);
+          ys[r * d.c_out + k] = v;
+        }
+      }
+    }
+    __syncthreads();
+    adv_copy(d.pred + (size_t)row0 * d.c_out, ys, rows * d.c_out, vec & 8, t);
   }
 }
 
@@ -1686,8 +1737,24 @@ int gc_advance_state(const gc_advance_desc* dp, void* stream) {
   if (d.n_forc > 0 && (!d.f_cur || !d.f_next)) return fail(GC_EINVAL, "gc_advance_state: forcings missing");
   if (d.pred && (!d.p_src_x || !d.p_ax || !d.p_ay || !d.p_b))
     return fail(GC_EINVAL, "gc_advance_state: prediction tables missing");
-  hipLaunchKernelGGL(advance_state_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), d);
+  const size_t lds = ((((size_t)kAdvRows * d.c_in + 3) & ~(size_t)3) * 2 + (((size_t)kAdvRows * d.c_out + 3) & ~(size_t)3)) * sizeof(float);
+  if (d.c_in > 256 * kAdvMaxJ || d.c_out > 256 * kAdvMaxJ) return fail(GC_EINVAL, "gc_advance_state: more than 1024 channels");
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&advance_state_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+      return GC_ELAUNCH;
+    }
+    lds_set = lds;
+  }
+  // 16-byte copies where base and row-block stride allow (bit 0 x, 1 y, 2 x_next, 3 pred)
+  auto vec_ok = [](const void* p, int c) { return (reinterpret_cast<size_t>(p) & 15) == 0 && ((kAdvRows * c) & 3) == 0; };
+  const int vec = (vec_ok(d.x, d.c_in) ? 1 : 0) | (vec_ok(d.y, d.c_out) ? 2 : 0) | (vec_ok(d.x_next, d.c_in) ? 4 : 0) |
+                  (d.pred && vec_ok(d.pred, d.c_out) ? 8 : 0);
+  hipLaunchKernelGGL(advance_state_kernel, dim3((d.n_rows + kAdvRows - 1) / kAdvRows), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), d, vec);
   return check_launch("advance_state_kernel");
 }
 

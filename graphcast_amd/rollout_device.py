@@ -213,10 +213,24 @@ class DeviceRollout:
       d.pred = traj[s if keep_trajectory else 0].data_ptr()
       nat.check(self._lib.gc_advance_state(ctypes.byref(d), stream()), "gc_advance_state")
       x, x_next = x_next, x
+      self._last_advance = (d, x, x_next, y)          # (keeps the buffers of the descriptor alive)
     ev1.record()
     self.final_state = x
     self._loop_events = (ev0, ev1)
     return traj
+
+  def advance_ms(self, iters: int = 20) -> float:
+    """Device time of one gc_advance_state launch (the last step's descriptor replayed), milliseconds."""
+    d = self._last_advance[0]
+    s = ctypes.c_void_p(torch.cuda.current_stream(torch.device(self._model._device)).cuda_stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nat.check(self._lib.gc_advance_state(ctypes.byref(d), s), "gc_advance_state")
+    ev0.record()
+    for _ in range(iters):
+      nat.check(self._lib.gc_advance_state(ctypes.byref(d), s), "gc_advance_state")
+    ev1.record()
+    ev1.synchronize()
+    return ev0.elapsed_time(ev1) / iters
 
   def last_loop_ms(self) -> float:
     """Device time of the last run()'s step loop (steps + state advances), milliseconds."""

@@ -28,6 +28,7 @@ def main():
   ap.add_argument("--res", type=float, default=0.25)
   ap.add_argument("--mesh", type=int, default=6)
   ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "rollout.json"))
+  ap.add_argument("--precision", default=None, help='None = f16x3 (fp32-grade); "bf16" = the Bfloat16Cast tier')
   args = ap.parse_args()
   task = gc.TASK
   lat = np.arange(-90, 90 + args.res / 2, args.res)
@@ -38,6 +39,7 @@ def main():
                        hidden_layers=1, radius_query_fraction_edge_length=0.6)
   t0 = time.perf_counter()
   model = gc.GraphCast(cfg, task, params=gparams.random_params(c_in, c_out, 512, 16))
+  model.set_precision(args.precision)
   inputs, template, forcings = synthetic.make_example(task, lat, lon, num_target_steps=args.steps)
   mean, std, dstd = synthetic.make_stats(task)
   roll = rollout_device.DeviceRollout(model, std, mean, dstd)
@@ -50,10 +52,14 @@ def main():
   torch.cuda.synchronize()
   total = time.perf_counter() - t0
   loop_ms = roll.last_loop_ms()          # the device loop alone: steps + fused state advances
+  advance_ms = roll.advance_ms()
+  n_rows = traj.shape[1] * traj.shape[2]
+  advance_bytes = 4.0 * n_rows * (2 * c_in + 2 * c_out + 2 * 5)      # x in, x_next out, y in, prediction out, forcings
   finite = bool(torch.isfinite(traj).all().item())
   res = {"config": f"GraphCast {args.res} deg / {len(task.pressure_levels)} levels / M{args.mesh}, "
                    f"{args.steps} x 6 h autoregressive rollout, HBM-resident (DeviceRollout)",
          "steps": args.steps, "device_loop_ms": loop_ms, "ms_per_step": loop_ms / args.steps,
+         "advance_state_ms": advance_ms, "advance_state_gb_per_s": advance_bytes / advance_ms / 1e6,
          "steps_per_second": 1e3 * args.steps / loop_ms,
          "seconds_total_including_host_prep_and_upload": total,
          "trajectory_gb_in_hbm": traj.numel() * 4 / 1e9, "finite": finite,

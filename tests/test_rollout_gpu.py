@@ -196,3 +196,38 @@ def test_bfloat16_cast_wrapper(setup):
         f"restatement of the reference's bf16 run {d_ref:.2e}; HIP vs restatement {between:.2e}")
   assert 1e-4 < d_hip <= 1.25 * d_ref
   assert between <= 2.0 * d_ref
+
+
+def test_device_rollout_in_the_bfloat16_tier(setup):
+  """The reference's standard chain -- rollout(InputsAndResiduals(Bfloat16Cast(GraphCast))) -- against
+  rollout_device.DeviceRollout with the model switched to its "bf16" arithmetic: the kernels round
+  the fp32 state to bfloat16 on read (GC_ROWS_F32) and emit bfloat16-valued fp32 predictions, which is
+  exactly what the wrapper's casts do around the step; the two differ by the fp32 rounding of the
+  normalisation algebra, which can move an input across a bfloat16 rounding boundary (hence the
+  tolerance at bfloat16 resolution)."""
+  from graphcast_amd import casting
+  from graphcast_amd import rollout_device
+  model, _ = setup
+  n_steps = 3
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, batch=2,
+                                                      num_target_steps=n_steps, seed=17)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  dut = normalization.InputsAndResiduals(casting.Bfloat16Cast(model), std, mean, dstd)
+  put = lambda ds: synthetic.to_device(ds, "cuda:0")
+  want = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
+                                    device_put_fn=put)
+  fp32 = rollout.chunked_prediction(
+      lambda rng, **kw: normalization.InputsAndResiduals(model, std, mean, dstd)(**kw), None, inputs, template,
+      forcings, device_put_fn=put)
+  with casting.precision_view(model, "bf16"):
+    roll = rollout_device.DeviceRollout(model, std, mean, dstd)
+    got = roll.to_dataset(roll.run(inputs, template, forcings), template)
+  assert model._precision is None
+  worst = tier = 0.0
+  for k in template.keys():
+    worst = max(worst, _rel(got[k].values, want[k].values))
+    tier = max(tier, _rel(want[k].values, fp32[k].values))
+  print(f"bf16 tier, {n_steps}-step device rollout vs the wrapper chain: worst per-variable rel diff {worst:.2e} "
+        f"(the tier's own distance to the fp32-grade rollout: {tier:.2e})")
+  assert worst <= tier              # closer to the wrapper chain than the tier is to fp32
+  assert worst < 2e-2
