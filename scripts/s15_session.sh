@@ -2,6 +2,7 @@
 # Round-3 session 15: upper bound of what cheaper correction products could buy -- profiling libraries
 # that DROP one (hdrop1) or both (hdrop3) correction MFMAs of every f16x3 product (results wrong by
 # construction): single launches, then the whole step with the library swapped in (scratch copy only).
+# (libraries: scripts/probes/build_probe_lib.sh f16x3_drop_correction_mfmas.patch ab_libs/libgcast_hdrop<bits>.so -DGC_H_DROP=<bits>)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${1:-s15}
