@@ -18,6 +18,7 @@ PREC_F32, PREC_F16X3, PREC_BF16_GEMM, PREC_BF16 = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16gemm": PREC_BF16_GEMM, "bf16": PREC_BF16}
 ROWS_F32 = 1                                      # GC_ROWS_F32 (gc_rowmlp_desc.flags)
 W2_NATURAL = 2                                    # GC_W2_NATURAL
+WG_ROWS_64, WG_ROWS_128 = 4, 8                    # GC_WG_ROWS_64 / GC_WG_ROWS_128 (GC_PREC_BF16: pin the rows per workgroup)
 LAYOUT_CHUNKED, LAYOUT_HALF = 0, 2
 LATENT = 512
 TILE_ROWS = 64

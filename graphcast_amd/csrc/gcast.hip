@@ -1467,7 +1467,8 @@ bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};
 // Rows per workgroup of a GC_PREC_BF16 launch: 64 (two workgroups per CU), or 128 (eight waves sharing
 // one weight stream, one workgroup per CU) for the big node-side launches -- no gather, no segment-sum,
 // at least kBfWideMinRows rows: measured 6-7 % faster there, 1-7 % slower on the edge updates
-// (profiles/r03_s12_*).  GCAST_BF16_ROWS=64|128 (read once) pins the choice for A/B runs.
+// (profiles/r03_s12_*).  gc_rowmlp_desc.flags GC_WG_ROWS_64 / _128 pin the choice per launch,
+// GCAST_BF16_ROWS=64|128 (read once) for a whole process (A/B runs of bench.py).
 constexpr int kBfWideMinRows = 128 * 256 * 2;
 int bf16_rows_override() {
   static const int v = [] {
@@ -1498,7 +1499,7 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
 
 template <bool F32ROWS>
 int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
-  const int pin = bf16_rows_override();
+  const int pin = (d.flags & GC_WG_ROWS_128) ? 128 : (d.flags & GC_WG_ROWS_64) ? 64 : bf16_rows_override();
   const bool wide = pin == 128 || (pin != 64 && d.n_rows >= kBfWideMinRows && !d.seg && !d.g0 && !d.g1);
   return wide ? launch_rowmlp_bf16<F32ROWS, 8>(d, s) : launch_rowmlp_bf16<F32ROWS, 4>(d, s);
 }

@@ -102,6 +102,11 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
                                   * Same arithmetic as the two-pass launch up to the summation order inside an
                                   * MFMA (csrc/rowmlp_half.inc, ONEPASS). */
 
+#define GC_WG_ROWS_64 4          /* GC_PREC_BF16: pin the rows per workgroup -- 64 (four waves, two workgroups per CU) */
+#define GC_WG_ROWS_128 8         /* or 128 (eight waves sharing one weight stream, one workgroup per CU).  Neither
+                                  * flag: chosen per launch (128 for launches without gather / segment-sum from
+                                  * 65,536 rows on).  Results are bit-identical either way. */
+
 /* How w1p / w2p are packed, i.e. which tile formulation runs.
  *   GC_LAYOUT_CHUNKED  the layouts described above: 32-row K chunks staged through LDS, every wave
  *                      owns 16 rows of the tile and reads the whole chunk (all modes, all precisions).

@@ -141,6 +141,12 @@ def test_node_like_launch_with_residual(dev, n_rows, k0, k1):
   first = out.clone()
   run(d)
   assert torch.equal(first, out)                                  # bitwise repeatable
+  for pin in (nat.WG_ROWS_64, nat.WG_ROWS_128):                   # 64- and 128-row workgroups: the same bits
+    out.zero_()
+    d.flags = pin
+    run(d)
+    assert torch.equal(first, out), pin
+  d.flags = 0
   z = rb(p["a"]) @ rb(p["w1"]) + rb(p["b1"])
   e = mlp_ln_want(z, p)
   want = rb(rb(res) + e)
@@ -191,15 +197,26 @@ def test_edge_launch_with_gathers_and_segment_sum(dev, kind):
   d.seg, d.tile_flags, d.agg, d.partial = t["rcv"].data_ptr(), t["flags"].data_ptr(), agg.data_ptr(), partial.data_ptr()
   lib = nat.lib()
   stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-  nat.check(lib.gc_rowmlp(ctypes.byref(d), stream), "gc_rowmlp")
-  if len(pk.fix_recv):
-    f = [up(x, dev, np.int32) for x in (pk.fix_recv, pk.fix_t0, pk.fix_t1)]
-    nat.check(lib.gc_seg_fixup_bf16(len(pk.fix_recv), f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(),
-                                    partial.data_ptr(), agg.data_ptr(), stream), "gc_seg_fixup_bf16")
-  if len(pk.empty_receivers):
-    zr = up(pk.empty_receivers, dev, np.int32)
-    nat.check(lib.gc_zero_rows_bf16(len(zr), zr.data_ptr(), agg.data_ptr(), stream), "gc_zero_rows_bf16")
-  torch.cuda.synchronize()
+
+  def launch(flags):
+    agg.fill_(float("nan")); partial.fill_(float("nan")); out.zero_()
+    d.flags = flags
+    nat.check(lib.gc_rowmlp(ctypes.byref(d), stream), "gc_rowmlp")
+    if len(pk.fix_recv):
+      f = [up(x, dev, np.int32) for x in (pk.fix_recv, pk.fix_t0, pk.fix_t1)]
+      nat.check(lib.gc_seg_fixup_bf16(len(pk.fix_recv), f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(),
+                                      partial.data_ptr(), agg.data_ptr(), stream), "gc_seg_fixup_bf16")
+    if len(pk.empty_receivers):
+      zr = up(pk.empty_receivers, dev, np.int32)
+      nat.check(lib.gc_zero_rows_bf16(len(zr), zr.data_ptr(), agg.data_ptr(), stream), "gc_zero_rows_bf16")
+    torch.cuda.synchronize()
+    return out.clone(), agg.clone()
+
+  wide = launch(nat.WG_ROWS_128)                    # eight-wave workgroups (two packed edge tiles each; odd tile counts too)
+  narrow = launch(nat.WG_ROWS_64)
+  assert torch.equal(wide[0], narrow[0]) and torch.equal(wide[1].view(torch.int16), narrow[1].view(torch.int16))
+  launch(0)
+  assert torch.equal(out, narrow[0]) and torch.equal(agg.view(torch.int16), narrow[1].view(torch.int16))
   ok = pk.receivers >= 0
   z = rb(dd) + rb(gs)[np.maximum(pk.senders, 0)] + rb(gr)[np.maximum(pk.receivers, 0)] + rb(p["b1"])
   if use_rows:
@@ -271,7 +288,13 @@ def test_external_rows_and_chained_stages(dev, n_rows, c_in):
   d.out, d.ldo = out.data_ptr(), D
   d.n_chain = 1
   _chain(d, 0, t["ws"], nat.CHAIN_ROWS, out=pre, ldo=D)
+  d.flags = nat.ROWS_F32 | nat.WG_ROWS_128
   run(d)
+  wide = (out.clone(), pre.clone())
+  out.zero_(); pre.zero_()
+  d.flags = nat.ROWS_F32 | nat.WG_ROWS_64
+  run(d)
+  assert torch.equal(wide[0], out) and torch.equal(wide[1], pre)         # 128- and 64-row workgroups: the same bits
   xin = np.concatenate([x[:, b], st], axis=1)
   rows_want = mlp_ln_want(rb(xin) @ rb(p["w1"]) + rb(p["b1"]), p)
   err, ulps = rel_rmse(down_rows(out), rows_want), ulp_rms(down_rows(out), rows_want)
@@ -283,7 +306,13 @@ def test_external_rows_and_chained_stages(dev, n_rows, c_in):
   d.n_chain = 2
   _chain(d, 0, t["wh"], nat.CHAIN_SWISH, b=t["bh"])
   _chain(d, 1, t["wo"], nat.CHAIN_NARROW, b=t["bo"], out=y, ldo=n_out, n=n_out)
+  d.flags = nat.ROWS_F32 | nat.WG_ROWS_128
   run(d)
+  y_wide = y.clone()
+  y.zero_()
+  d.flags = nat.ROWS_F32 | nat.WG_ROWS_64
+  run(d)
+  assert torch.equal(y_wide, y)
   with ognn.activations("bf16"):
     y_want = ognn.linear(ognn.swish(ognn.linear(got_rows.astype(np.float32), w_hid, bh)), w_o, bo[:n_out]).astype(np.float64)
   err_y, ulp_y = rel_rmse(y.cpu().numpy(), y_want), ulp_rms(y.cpu().numpy(), y_want)
