@@ -30,4 +30,15 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/pmc_$C.json" 2> "$OLDPWD/$OUT/pmc_$C.err"); echo "pmc $C rc=$?"
 done
 python scripts/pmc_by_stage.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" > "$OUT/pmc_by_stage.json" 2>> "$OUT/errors.txt"; head -c 400 "$OUT/pmc_by_stage.json"; echo
+if [ "${DO_SQ:-1}" = "1" ]; then
+  i=0
+  for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_ADDR_CONFLICT"; do
+    i=$((i + 1))
+    echo "== rocprofv3 --pmc (SQ set $i)"
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OLDPWD/$OUT/pmc_sq$i" -o pmc -- \
+        python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/pmc_sq$i.json" 2> "$OLDPWD/$OUT/pmc_sq$i.err"); echo "pmc sq$i rc=$?"
+  done
+  python scripts/sq_by_stage.py "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/sq_by_stage.json" 2>> "$OUT/errors.txt"; python -c "
+import json; j=json.load(open('$OUT/sq_by_stage.json')); print({k: {m: round(v[m], 3) for m in ('mfma_busy_per_simd', 'wave_waiting', 'wave_waiting_on_lds', 'lds_bank_conflict') if m in v} for k, v in j.items()})"
+fi
 find "$OUT" -type f -size +8M -delete
