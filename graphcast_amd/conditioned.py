@@ -19,7 +19,6 @@ bias).  Edge embeddings depend on the conditioning here, so nothing is constant-
 
 The sparse-transformer processor between the two (``denoiser.py:331-339``) is out of scope.
 """
-import ctypes
 from typing import Mapping, Optional
 
 import numpy as np

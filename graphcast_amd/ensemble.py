@@ -11,9 +11,8 @@ is RCCL on ROCm; the CPU tests run the same code over ``gloo``.
 
 ``WithSampleDim`` mirrors ``weathernext/utils/ensemble.py:22-55``.
 """
-from typing import Any, Callable, Dict, List, Optional, Sequence
+from typing import Any, Callable, Dict, List, Optional
 
-import numpy as np
 
 from graphcast_amd import predictor_base
 from graphcast_amd import xarray_lite as xarray

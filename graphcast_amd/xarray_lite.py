@@ -28,7 +28,7 @@ the state on the GPU); every operation used here works on both.
 """
 import collections.abc
 import math
-from typing import Any, Dict, Mapping, Optional, Sequence
+from typing import Any, Dict, Mapping, Sequence
 
 import numpy as np
 
