@@ -11,7 +11,9 @@ summed over SIMDs = 16 x #MFMA for the 16x16x32 shapes):
   wave_waiting_on_lds  = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
   lds_bank_conflict    = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 
-    python scripts/sq_by_stage.py <pass dir> [<pass dir> ...] > profiles/r03_..._sq_by_stage.json
+    python scripts/sq_by_stage.py <pass dir | counter csv> [...] > profiles/r03_..._sq_by_stage.json
+    (the committed summary is reproducible from the committed rows:
+     python scripts/sq_by_stage.py profiles/r03_final2_pmc_sq1_rowmlp_launches.csv profiles/r03_final2_pmc_sq2_rowmlp_launches.csv)
 """
 import csv
 import glob
@@ -27,7 +29,8 @@ STAGES = (["enc_embed_grid", "enc_edge", "enc_node_mesh", "enc_node_grid"]
 def main():
   per = defaultdict(dict)           # counter -> {dispatch id: value}
   for root in sys.argv[1:]:
-    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    files = [root] if os.path.isfile(root) else glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)
+    for f in files:
       with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
           k = r["Kernel_Name"]

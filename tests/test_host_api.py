@@ -590,3 +590,25 @@ def test_arithmetic_aligns_on_level_labels_like_the_reference_normalisation():
   assert rollout_device._stat(mean, "absent", 500, 7.0) == 7.0
   with pytest.raises(KeyError):
     rollout_device._stat(mean, "temperature", 501, 0.0)
+
+
+def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows():
+  """profiles/r03_final2_sq_by_stage.json (MFMA pipe busy per stage) is what
+  scripts/sq_by_stage.py computes from the committed rocprofv3 counter rows of the same session."""
+  import json
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  rows = [os.path.join(root, "profiles", f"r03_final2_pmc_sq{i}_rowmlp_launches.csv") for i in (1, 2)]
+  out = subprocess.run([sys.executable, os.path.join(root, "scripts", "sq_by_stage.py"), *rows], check=True,
+                       capture_output=True, text=True).stdout
+  got = json.loads(out)
+  with open(os.path.join(root, "profiles", "r03_final2_sq_by_stage.json")) as f:
+    want = json.load(f)
+  assert got.keys() == want.keys() and len(got) == 8
+  for stage in want:
+    for k, v in want[stage].items():
+      assert abs(got[stage][k] - v) <= 1e-9 * max(1.0, abs(v)), (stage, k)
+  assert 0.3 < got["proc_edge"]["mfma_busy_per_simd"] < 0.6
+  assert got["proc_edge"]["lds_bank_conflict"] == 0.0
