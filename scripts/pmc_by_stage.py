@@ -22,7 +22,8 @@ STAGES = (["enc_embed_grid", "enc_edge", "enc_node_mesh", "enc_node_grid"]
 
 def rowmlp_values(root, kernel_sub):
   rows = []
-  for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+  files = [root] if os.path.isfile(root) else glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)
+  for f in files:
     with open(f, newline="") as fh:
       for r in csv.DictReader(fh):
         if kernel_sub in r["Kernel_Name"] and "<0" not in r["Kernel_Name"]:

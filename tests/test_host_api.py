@@ -612,3 +612,26 @@ def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows():
       assert abs(got[stage][k] - v) <= 1e-9 * max(1.0, abs(v)), (stage, k)
   assert 0.3 < got["proc_edge"]["mfma_busy_per_simd"] < 0.6
   assert got["proc_edge"]["lds_bank_conflict"] == 0.0
+
+
+def test_committed_traffic_summary_is_reproducible_from_the_committed_counter_rows():
+  """profiles/r03_final2_pmc_by_stage.json (L2 <-> fabric bytes per stage; roofline.traffic reads its processor
+  edge entry through profiles/pmc_traffic.json) from the committed FETCH_SIZE / WRITE_SIZE rows."""
+  import json
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  rows = [os.path.join(root, "profiles", f"r03_final2_pmc_{c}_rowmlp_launches.csv") for c in ("FETCH_SIZE", "WRITE_SIZE")]
+  out = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_by_stage.py"), *rows], check=True,
+                       capture_output=True, text=True).stdout
+  got = json.loads(out)
+  with open(os.path.join(root, "profiles", "r03_final2_pmc_by_stage.json")) as f:
+    want = json.load(f)
+  for stage in want:
+    for k, v in want[stage].items():
+      if isinstance(v, (int, float)):
+        assert abs(got[stage][k] - v) <= 1e-9 * max(1.0, abs(v)), (stage, k)
+  with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
+    table = json.load(f)
+  assert table["f16x3h:proc_edge"]["bytes_per_launch"] == want["proc_edge"]["traffic_bytes_per_launch"]
