@@ -70,6 +70,24 @@ def measured_traffic(kernel_key):
   return table.get(kernel_key)
 
 
+def measured_mfma_busy(kernel_key):
+  """MFMA pipe busy fraction of the dominant launch from the committed rocprofv3 SQ counter passes of the SAME
+  command (profiles/r03_final2_sq_by_stage.json via scripts/sq_by_stage.py: SQ_VALU_MFMA_BUSY_CYCLES over the
+  SIMD cycles of two resident waves); like `traffic`, attached from the profile because bench.py cannot run
+  rocprofv3 on itself.  None when no profile of this kernel is committed."""
+  if not kernel_key.startswith("f16x3h:"):
+    return None
+  path = os.path.join(ROOT, "profiles", "r03_final2_sq_by_stage.json")
+  try:
+    with open(path) as f:
+      stage = json.load(f)[kernel_key.split(":")[1]]
+  except (OSError, ValueError, KeyError):
+    return None
+  return {"mfma_busy_per_simd": stage.get("mfma_busy_per_simd"), "wave_waiting": stage.get("wave_waiting"),
+          "lds_bank_conflict": stage.get("lds_bank_conflict"),
+          "source": "profiles/r03_final2_sq_by_stage.json (scripts/sq_by_stage.py on the committed counter rows)"}
+
+
 def fast_params(c_in, c_out, steps, seed=1):
   """Random-init weights of the architecture in the reference's haiku layout."""
   from graphcast_amd import params as gparams
@@ -320,6 +338,7 @@ def main():
             "avg_launch_ms": dom["ms"] / dom["launches"],
             "traffic": (measured_traffic(traffic_key) or {}).get("bytes_per_launch"),
             "traffic_source": (measured_traffic(traffic_key) or {}).get("source"),
+            "pmc": measured_mfma_busy(traffic_key),
             "step_executed_tflop": executed_tflop,
             "step_as_written_tflop": f_alg / 1e12,
             "step_frac_executed": executed_tflop / (ms_per_step / 1e3) / peak,
