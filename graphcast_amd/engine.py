@@ -477,7 +477,8 @@ class StepEngine:
     pi = torch.from_numpy(packing.PI_PERM).to(dev)
     to_bf = lambda t: t.index_select(1, pi).to(torch.bfloat16).contiguous()
     if any(v is not None for v in base.halo.values()):
-      raise NotImplementedError("the GC_PREC_BF16 tier does not run spatially partitioned graphs")
+      raise NotImplementedError("the GC_PREC_BF16 tier runs partitioned graphs behind blocking exchanges only "
+                                "(GCAST_OVERLAP=1 splits edge updates and joins fp32 aggregate rows)")
     self.halo = dict(g2m=None, mesh=None, m2g=None)
     self.e_g2m, self.e_mesh, self.e_m2g = base.e_g2m, base.e_mesh, base.e_m2g
     self.grid_struct = base.grid_struct

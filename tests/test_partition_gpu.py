@@ -59,6 +59,33 @@ def test_partitioned_step_equals_full_step(setup, n_parts, overlap, monkeypatch)
   assert rel < 2e-6
 
 
+@pytest.mark.parametrize("n_parts", [2, 8])
+def test_partitioned_step_in_the_bfloat16_tier(setup, n_parts, monkeypatch):
+  """The same partition with every rank's engine in the "bf16" arithmetic (GC_PREC_BF16: bfloat16 row tables, so
+  the halo rows exchanged are bfloat16 too), behind blocking exchanges.  Partitioning moves tile boundaries, i.e.
+  the order of fp32 partial sums in front of ONE bfloat16 rounding: the two bf16 runs decorrelate at bfloat16
+  resolution, and must sit at the same distance from the fp32-grade step."""
+  from graphcast_amd import engine
+  monkeypatch.setenv("GCAST_OVERLAP", "0")
+  m = setup["model"]
+  full = engine.StepEngine(m.graph_arrays(), setup["params"], num_steps=setup["steps"], c_in=setup["c_in"],
+                           c_out=setup["c_out"], device="cuda:0", precision="bf16")
+  y_full = full.forward(setup["x"]).clone()
+  step = partition.EmulatedPartitionedStep(
+      m.graph_arrays(), setup["params"], m._grid_nodes_lon, m._mesh_nodes_lon, n_parts,
+      num_steps=setup["steps"], c_in=setup["c_in"], c_out=setup["c_out"], precision="bf16",
+      grid_lat=m._grid_nodes_lat, mesh_lat=m._mesh_nodes_lat)
+  y = step(setup["x"])
+  torch.cuda.synchronize()
+  assert torch.isfinite(y).all()
+  rel = lambda a, b: float(torch.linalg.vector_norm((a - b).double()) / torch.linalg.vector_norm(b.double()))
+  between, d_part, d_full = rel(y, y_full), rel(y, setup["y"]), rel(y_full, setup["y"])
+  print(f"bf16 tier, {n_parts} parts: vs the unpartitioned bf16 step {between:.2e}; distance to the fp32-grade step: "
+        f"partitioned {d_part:.2e}, unpartitioned {d_full:.2e}")
+  assert between < 2e-2
+  assert d_part < 1.25 * d_full + 1e-3
+
+
 def test_partitioned_step_against_oracle(setup):
   """And against the float64 oracle directly (the partition must not hide behind the engine)."""
   graphs = ogc.build_graphs(setup["lat"], setup["lon"], setup["mesh_size"])
