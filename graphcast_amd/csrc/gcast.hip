@@ -50,15 +50,16 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef GC_TRACE
 #define GC_TRACE 0       // profiling ONLY: rowmlp16 writes phase timestamps of wave 0 to d.partial
-#endif                   // (launches without segment-sum; scripts/kernel_probe.py)
+#endif                   // (launches without segment-sum; a profiling library: scripts/probes/build_probe_lib.sh)
 #ifndef GC_EXP
-#define GC_EXP 0         // profiling experiments ONLY (scripts/kernel_probe.py; results are wrong):
+#define GC_EXP 0         // profiling experiments ONLY on the chunked kernels (results are wrong; round-1 probes):
 #endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA,
                          // bit3 never wait for the DMA
 
 // Profiling switches that make a kernel compute WRONG results (GC_EXP: pieces of the work
 // removed) or write timestamps over result buffers (GC_TRACE, GC_H_TRACE) only compile in a build that
-// says so: scripts/kernel_probe.py / half_probe.py pass -DGC_PROFILING_BUILD, the product build
+// says so: scripts/probes/build_probe_lib.sh passes -DGC_PROFILING_BUILD (scripts/half_probe.py loads such a
+// library NEXT to the product one), the product build
 // (graphcast_amd/_native.py: build) never does, gc_build_info() reports it and the Python binding
 // refuses to load such a library as the product.
 #if (GC_EXP != 0 || GC_TRACE != 0) && !defined(GC_PROFILING_BUILD)
@@ -1443,6 +1444,25 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
 
 bool g_h_attr_set[3][4] = {};
 
+// A/B switches of the persistent GC_LAYOUT_HALF launches, read once per process (measurement runs of bench.py):
+// GCAST_GRID_CAP=<n <= GC_SCRATCH_SLOTS> workgroups per launch (256 = one per CU), GCAST_TILE_MAP=xcd|rr the
+// tile -> workgroup map (GC_TILE_XCD; a launch can also ask for it in gc_rowmlp_desc.flags).
+int half_grid_cap() {
+  static const int v = [] {
+    const char* e = std::getenv("GCAST_GRID_CAP");
+    const int n = e ? std::atoi(e) : 0;
+    return n > 0 && n <= GC_SCRATCH_SLOTS ? n : GC_SCRATCH_SLOTS;
+  }();
+  return v;
+}
+bool half_tile_xcd() {
+  static const bool v = [] {
+    const char* e = std::getenv("GCAST_TILE_MAP");
+    return e && std::strcmp(e, "xcd") == 0;
+  }();
+  return v;
+}
+
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = kHLdsFloats * sizeof(float);
@@ -1457,8 +1477,11 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   }
   // persistent workgroups: two per CU on the 256 CUs of an MI355X, each walking tiles b, b + grid, ...
   const int tiles = (d.n_rows + kHRows - 1) / kHRows;
-  const int grid = tiles < GC_SCRATCH_SLOTS ? tiles : GC_SCRATCH_SLOTS;
-  hipLaunchKernelGGL((rowmlp16h_kernel<MODE, ONEPASS>), dim3(grid), dim3(256), lds, s, d);
+  const int cap = half_grid_cap();
+  const int grid = tiles < cap ? tiles : cap;
+  gc_rowmlp_desc dd = d;
+  if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
+  hipLaunchKernelGGL((rowmlp16h_kernel<MODE, ONEPASS>), dim3(grid), dim3(256), lds, s, dd);
   return check_launch("rowmlp16h_kernel");
 }
 
@@ -1586,6 +1609,8 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
     if (d.mode == GC_MODE_MLP_LN && !(d.flags & GC_W2_NATURAL) && (!d.scratch || !aligned16(d.scratch)))
       return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF + GC_MODE_MLP_LN needs a 16-byte aligned scratch");
   }
+  if (d.range_flag && (d.layout != GC_LAYOUT_HALF || d.prec != GC_PREC_F16X3 || (reinterpret_cast<size_t>(d.range_flag) & 3)))
+    return fail(GC_EINVAL, "gc_rowmlp: range_flag is a GC_PREC_F16X3 + GC_LAYOUT_HALF feature (4-byte aligned device word)");
   if (d.n_chain != 0) {
     if (d.layout != GC_LAYOUT_HALF || d.mode != GC_MODE_MLP_LN || d.seg)
       return fail(GC_EINVAL, "gc_rowmlp: a chain needs GC_LAYOUT_HALF + GC_MODE_MLP_LN without segment-sum");

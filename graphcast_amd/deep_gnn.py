@@ -119,8 +119,9 @@ class DeepGNN(engine.StepEngine):
     return view
 
   def _build_mlps(self, edge_name, recv_set, send_set):
-    if self._mlps is not None:
-      return self._mlps
+    key = (edge_name, recv_set, send_set)
+    if self._mlps is not None and self._mlps[0] == key:
+      return self._mlps[1]
     nodes = [recv_set] + ([send_set] if send_set != recv_set else [])
     out = []
     for i in range(self._steps):
@@ -130,15 +131,17 @@ class DeepGNN(engine.StepEngine):
           recv=engine._Mlp(view, "N0", self.dev, prec=self.prec),
           send=engine._Mlp(view, "N1", self.dev, prec=self.prec) if len(nodes) > 1 else None))
     self._keep.append(out)
-    self._mlps = out
+    self._mlps = (key, out)          # (a graph with other set names reads other parameter modules: rebuilt)
     return out
 
-  def _edges_of(self, senders, receivers, n_recv):
+  def _edges_of(self, senders, receivers, n_recv, n_send):
     s, r = np.asarray(senders).astype(np.int64), np.asarray(receivers).astype(np.int64)
-    key = (len(s), n_recv, hash(s.tobytes()), hash(r.tobytes()))
+    key = (n_recv, n_send, s.tobytes(), r.tobytes())       # (the index bytes themselves: no hash collisions)
     if key not in self._graphs:
       if len(r) and (r.min() < 0 or r.max() >= n_recv):
         raise NotImplementedError("DeepGNN on MI355X: padding edges (receiver index outside the node set) are not built")
+      if len(s) and (s.min() < 0 or s.max() >= n_send):
+        raise ValueError(f"DeepGNN: sender index outside the sender node set (0 <= s < {n_send})")
       e = engine._Edges(packing.pack_edges(s, r, n_recv), self.dev)
       ok = e.pk.perm >= 0
       e.src = torch.from_numpy(np.where(ok, e.pk.perm, 0).astype(np.int64)).to(self.dev)       # packed row -> edge
@@ -169,7 +172,7 @@ class DeepGNN(engine.StepEngine):
         raise ValueError(f"{what} features must be float32 [rows, batch, {D}] tensors on {self.dev}")
     batch = h_recv.shape[1]
     n_recv, n_send = h_recv.shape[0], h_send.shape[0]
-    edges = self._edges_of(eset.indices.senders, eset.indices.receivers, n_recv)
+    edges = self._edges_of(eset.indices.senders, eset.indices.receivers, n_recv, n_send)
     mlps = self._build_mlps(ekey.name, recv_set, send_set)
     same = send_set == recv_set
     new = lambda rows: torch.empty((rows, D), dtype=torch.float32, device=self.dev)
@@ -177,8 +180,10 @@ class DeepGNN(engine.StepEngine):
     out_e = torch.empty_like(e_in)
     pre_s, pre_r, agg = new(n_send), new(n_recv), new(n_recv)
     for b in range(batch):
-      hr = h_recv[:, b].contiguous()
-      hs = hr if same else h_send[:, b].contiguous()
+      # private copies: the node launches below write in place (res = out = hr / hs), and with batch == 1
+      # `h_recv[:, b].contiguous()` is a VIEW of the caller's tensor -- the reference never modifies its input
+      hr = h_recv[:, b].clone()
+      hs = hr if same else h_send[:, b].clone()
       e = e_in[:, b].index_select(0, edges.src)                        # packed rows (padding rows: edge 0, masked by seg = -1)
       ops = []
       for _ in range(self._reps):

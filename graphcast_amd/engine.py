@@ -176,6 +176,10 @@ class StepEngine:
       half = os.environ.get("GCAST_HALF", DEFAULT_HALF) == "1"
     self.half = (bool(half) and self.prec == nat.PREC_F16X3) or self.prec == nat.PREC_BF16
     self.scratch = None
+    # f16x3 half-N kernels: the device word the launches fed by EXTERNAL rows set when a value exceeds the exact
+    # range of the split halves (include/gcast.h: gc_rowmlp_desc.range_flag); read by check_range()
+    self.range_flag = (torch.zeros((1,), dtype=torch.int32, device=self.dev)
+                       if self.half and self.prec == nat.PREC_F16X3 else None)
     # chained Linear layers + in-place grid input (only the half-N kernels have them); GCAST_FUSE=0
     # keeps one launch per reference layer group for A/B runs
     self.onepass = os.environ.get("GCAST_ONEPASS", "1") == "1"     # (0: the two-pass launches everywhere, for A/B runs)
@@ -218,8 +222,10 @@ class StepEngine:
   def _desc(self, mode, n_rows, *, a0=None, k0=0, lda0=None, a1=None, k1=0, lda1=None, w1p=None,
             d=None, g0=None, idx0=None, g1=None, idx1=None, b1=None, w2p=None, b2=None, n2=0,
             ln=None, res=None, out=None, ldo=None, out_ptr=None, edges: Optional[_Edges] = None,
-            agg=None, chain=(), rows_f32=False, w2_natural=None):
+            agg=None, chain=(), rows_f32=False, w2_natural=None, check_range=False):
     ds = nat.RowMlpDesc()
+    if check_range and self.range_flag is not None:
+      ds.range_flag = self.range_flag.data_ptr()
     ds.flags = nat.ROWS_F32 if (rows_f32 and self.prec == nat.PREC_BF16) else 0
     ds.mode, ds.n_rows, ds.prec = mode, n_rows, self.prec
     ds.a0, ds.k0, ds.lda0 = nat.ptr(a0), k0, (lda0 if lda0 is not None else (a0.shape[1] if a0 is not None else 0))
@@ -529,7 +535,7 @@ class StepEngine:
       # ---- encoder (grid2mesh GNN) ----
       m = self.m_enc_grid
       ops.append(self._op_mlp("enc_embed_grid", self._mlp_ln(
-          ng, m, a0=self.xin, k0=self.kp, w1p=m.w1, b1=m.b1, out=self.h_grid)))
+          ng, m, a0=self.xin, k0=self.kp, w1p=m.w1, b1=m.b1, out=self.h_grid, check_range=True)))
       m = self.m_g2m_edge
       ops.append(self._op_mlp("enc_pre", self._desc(
           nat.MODE_LINEAR, ng, a0=self.h_grid, k0=D, w1p=m.w1["s"], out=self.pre_grid)))
@@ -657,6 +663,7 @@ class StepEngine:
         src = dict(a0=self.xin, k0=k_full, lda0=batch * self.c_in, a1=self.xin, k1=kt, lda1=kt, rows_f32=True)
       else:                # fewer than 32 input channels: the tail [x | struct | 0] is the whole input
         src = dict(a0=self.xin, k0=kt, lda0=kt, rows_f32=True)
+      src["check_range"] = True        # the one launch fed by external rows (check_range())
       ops.append(self._op_mlp("enc_embed_grid", self._mlp_ln(
           ng, m, w1p=m.w1, b1=m.b1, out=self.h_grid, chain=[rows(self.m_g2m_edge, "s", self.pre_grid)],
           **src)))
@@ -731,6 +738,20 @@ class StepEngine:
 
   __call__ = forward
 
+  def check_range(self):
+    """Raises GcastRangeError if a step since the last call read an input value outside the exact range of the
+    f16x3 arithmetic (|x| > 65504: the split halves saturate -- 5e-4 errors up to 1.3e5, garbage beyond -- where
+    the reference's fp32 does not care; un-normalised geopotential is ~5e5).  SYNCHRONISES the launch stream:
+    call it where the host waits for the step anyway (GraphCast.__call__, DeviceRollout.run, bench.py do)."""
+    if self.range_flag is None:
+      return
+    if int(self.range_flag.item()) != 0:
+      self.range_flag.zero_()
+      raise nat.GcastRangeError(
+          f"an input value exceeds {nat.F16X3_MAX:g} in magnitude: outside the exact range of the f16x3 arithmetic "
+          "(precision='f16x3').  Normalise the inputs (normalization.InputsAndResiduals, as the reference's demo "
+          "stack does) or run with precision='f32'.")
+
   def run_until(self, x: torch.Tensor, tag: str, y: Optional[torch.Tensor] = None):
     """Enqueues the step's launches up to (not including) the first launch tagged `tag` (batch
     element 0) and returns how many ran: the workspace then holds that stage boundary -- e.g.
@@ -756,16 +777,24 @@ class StepEngine:
     # other tensors before they have all run (interleaved partitioned steps, time_ops, ...)
     arr = (nat.Op * len(bound))()
     ctypes.memmove(arr, bound, ctypes.sizeof(bound))
+    # ONE segment per cut (+ the tail), in program order, EMPTY segments included: every rank of a partitioned
+    # step then has the same segment / action structure whatever its own edge sets decided in `split` (a rank
+    # whose senders of a table are all local, or all remote, runs that edge update as one launch: its "start"
+    # and "wait" cuts coincide and the segment between them is empty) -- partition.py walks the ranks' segment
+    # lists in lockstep.
     cuts = self._cuts[x.shape[1]]
-    bounds = sorted({0, len(arr)} | {c for c, _, _ in cuts})
+    assert all(a[0] <= b[0] for a, b in zip(cuts[:-1], cuts[1:])), "cuts must be recorded in program order"
     segs = []
-    for lo, hi in zip(bounds[:-1], bounds[1:]):
+    lo = 0
+    for hi, actions in [(c, [(kind, name)]) for c, name, kind in cuts] + [(len(arr), [])]:
       sub = ctypes.cast(ctypes.byref(arr, lo * ctypes.sizeof(nat.Op)), ctypes.POINTER(nat.Op))
 
       def run(sub=sub, n=hi - lo, keep=arr):        # (`keep`: the copy lives as long as the closure)
-        with torch.cuda.device(self.dev):
-          nat.check(self.lib.gc_run_program(sub, n, self._stream_ptr()), "gc_run_program")
-      segs.append((run, [(kind, name) for c, name, kind in cuts if c == hi]))
+        if n > 0:
+          with torch.cuda.device(self.dev):
+            nat.check(self.lib.gc_run_program(sub, n, self._stream_ptr()), "gc_run_program")
+      segs.append((run, actions))
+      lo = hi
     return y, segs
 
   def halo_table(self, name: str) -> torch.Tensor:

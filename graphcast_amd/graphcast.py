@@ -293,6 +293,11 @@ class GraphCast(predictor_base.Predictor):
     else:
       x = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(self._device)
     y = self.forward_grid_node_features(x)
+    # the f16x3 arithmetic is exact only for |x| <= 65504 (normalised inputs are O(1)); the reference's fp32 takes
+    # anything: a step fed e.g. un-normalised geopotential RAISES here instead of returning wrong numbers.  (A
+    # synchronisation point: the host path copies y back right below; device-resident Dataset rollouts pay one
+    # stream wait per step -- rollout_device.DeviceRollout checks once per run instead.)
+    self._engine.check_range()
     return self._grid_node_outputs_to_prediction(y if on_device else y.cpu().numpy(),
                                                  targets_template)
 

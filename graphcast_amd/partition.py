@@ -265,6 +265,9 @@ class EmulatedPartitionedStep:
     xs = [x[torch.as_tensor(r.grid_owned, device=x.device)].contiguous() for r in self.ranks]
     bound = [e.segments(xl) for e, xl in zip(self.engines, xs)]
     n_seg = len(bound[0][1])
+    # (engine.segments: one segment per cut, so the structure does not depend on a rank's own split decisions)
+    assert all([a for _, a in segs] == [a for _, a in bound[0][1]] for _, segs in bound), \
+        "the ranks' segment / action lists differ"
     self.exchanges_per_call = 0
     compute = torch.cuda.current_stream(x.device)
     if self.overlap and self._comm is None:

@@ -94,6 +94,18 @@ class NativePlan:
 
   __call__ = forward
 
+  def check_range(self):
+    """gc_plan_check_range: synchronises the launch stream and raises GcastRangeError if the last step read an
+    input value outside the exact range of the f16x3 arithmetic (|x| > 65504)."""
+    if self._ws is None:
+      return
+    with torch.cuda.device(self.dev):
+      stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+      rc = self.lib.gc_plan_check_range(self._plan, self._ws.data_ptr(), stream)
+    if rc == nat.ERANGE:
+      raise nat.GcastRangeError(self.lib.gc_last_error().decode())
+    nat.check(rc, "gc_plan_check_range")
+
   def close(self):
     if self._plan:
       self.lib.gc_plan_destroy(self._plan)

@@ -217,10 +217,16 @@ class DeviceRollout:
     ev1.record()
     self.final_state = x
     self._loop_events = (ev0, ev1)
+    model._engine.check_range()        # (once per run: an out-of-range input state raises instead of a wrong trajectory)
     return traj
 
   def advance_ms(self, iters: int = 20) -> float:
-    """Device time of one gc_advance_state launch (the last step's descriptor replayed), milliseconds."""
+    """Device time of one gc_advance_state launch (the last step's descriptor replayed), milliseconds.
+
+    The replay REWRITES the last step's outputs (x_next and the last trajectory slot) with the same values;
+    call it right after run(), before those buffers are handed on."""
+    if getattr(self, "_last_advance", None) is None:
+      raise RuntimeError("DeviceRollout.advance_ms: no step has run yet (call run() with at least one step first)")
     d = self._last_advance[0]
     s = ctypes.c_void_p(torch.cuda.current_stream(torch.device(self._model._device)).cuda_stream)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -58,6 +58,8 @@ extern "C" {
 
 #define GC_EINVAL (-1)
 #define GC_ELAUNCH (-2)
+#define GC_ERANGE (-3)       /* gc_plan_check_range: an input row held |x| > GC_F16X3_MAX (see gc_rowmlp_desc.range_flag) */
+#define GC_F16X3_MAX 65504.0f  /* GC_PREC_F16X3 splits a row value into two halves, exact (20+ bits) for |x| <= this */
 
 /* Arithmetic of the two GEMMs of a launch.  Inputs, outputs, accumulation, bias,
  * LayerNorm, residual and segment-sum are fp32 in every mode.
@@ -106,6 +108,8 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
 #define GC_WG_ROWS_128 8         /* or 128 (eight waves sharing one weight stream, one workgroup per CU).  Neither
                                   * flag: chosen per launch (128 for launches without gather / segment-sum from
                                   * 65,536 rows on).  Results are bit-identical either way. */
+#define GC_TILE_XCD 16           /* GC_LAYOUT_HALF: tile -> workgroup map in which each XCD walks a contiguous eighth
+                                  * of the launch's tiles (csrc/rowmlp_half.inc).  A speed choice only. */
 
 /* How w1p / w2p are packed, i.e. which tile formulation runs.
  *   GC_LAYOUT_CHUNKED  the layouts described above: 32-row K chunks staged through LDS, every wave
@@ -212,6 +216,12 @@ typedef struct gc_rowmlp_desc {
   int n_chain;
   gc_chain_stage chain[GC_MAX_CHAIN];
   int flags;               /* GC_ROWS_F32 | ... (0 for everything but GC_PREC_BF16) */
+  /* GC_PREC_F16X3 + GC_LAYOUT_HALF, optional: a device word the launch sets to 1 when a layer-1 row value (a0 / a1)
+   * exceeds GC_F16X3_MAX in magnitude.  The split halves saturate there (exact to 6.5e4, 5e-4 up to 1.3e5, garbage
+   * beyond) where the reference's fp32 does not care -- launches fed by EXTERNAL rows (the grid embedder: un-normalised
+   * geopotential is ~5e5) pass it, the host reads it at its next synchronisation point and raises.  Never cleared
+   * by a launch.  NULL: no check (rows a LayerNorm has produced). */
+  int* range_flag;
 } gc_rowmlp_desc;
 
 int gc_rowmlp(const gc_rowmlp_desc* desc, void* stream);
@@ -364,6 +374,11 @@ int gc_plan_create(const gc_model_desc* model, const gc_tensor_desc* tensors, in
 size_t gc_plan_workspace_bytes(const gc_plan* plan, int batch);
 int gc_step_forward(const gc_plan* plan, const float* x, float* y, int batch, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* GC_PREC_F16X3 plans: gc_step_forward clears a range word in the workspace and the grid embedder sets it when an
+ * input value exceeds GC_F16X3_MAX (gc_rowmlp_desc.range_flag).  gc_plan_check_range synchronises `stream`, reads
+ * the word of the LAST gc_step_forward on this workspace and returns 0 or GC_ERANGE (message in gc_last_error):
+ * call it wherever the host synchronises anyway, before trusting y.  Other precisions: always 0. */
+int gc_plan_check_range(const gc_plan* plan, void* workspace, void* stream);
 void gc_plan_destroy(gc_plan* plan);
 
 /* Host-side packers the plan uses, exported so that a binding can check them bit for bit

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """BASELINE.json config 5: ONE 0.25 deg step strong-scaled over N GPUs -- the icosahedral
-multi-mesh and the grid partitioned by longitude band, receiver-owned edges, 18 halo exchanges
+multi-mesh and the grid partitioned by octant (hemispheres / quadrants for 2 / 4 ranks; partition.plan), receiver-owned edges, 18 halo exchanges
 per step (one RCCL all_to_all_single each).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -78,7 +78,7 @@ def main():
         "value": args.steps / float(t.item()), "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / args.steps,
         "higher_is_better": True, "scaling": "strong", "data": "synthetic",
-        "config": {"workload": f"GraphCast {args.config}, longitude-band partition x{world}, "
+        "config": {"workload": f"GraphCast {args.config}, octant partition x{world}, "
                                f"receiver-owned edges, 18 halo exchanges per step",
                    "rank0_rows": {"grid": mine.n_grid_owned, "mesh": mine.n_mesh_owned, "halo": halo}},
         "finite": bool(torch.isfinite(y).all().item())}))

@@ -58,7 +58,9 @@ class Config:
 
 
 CONFIGS = {"1deg": Config("1deg", RES, MESH, gc.TASK_13, N_STEPS, "rollout40_1deg_rows.npz"),
-           "0p25deg": Config("0p25deg", 0.25, 6, gc.TASK, 3, "rollout3_0p25deg_rows.npz")}
+           "0p25deg": Config("0p25deg", 0.25, 6, gc.TASK, 3, "rollout3_0p25deg_rows.npz"),
+           # BASELINE.json configs[2] itself: 40 autoregressive steps AT the headline size (round 4)
+           "0p25deg40": Config("0p25deg40", 0.25, 6, gc.TASK, 40, "rollout40_0p25deg_rows.npz")}
 
 
 def setup(config="1deg"):
@@ -113,14 +115,23 @@ def main(config="1deg", out_dir=HERE):
   torch_cpu.set_threads()
   ref = normalization.InputsAndResiduals(TorchOraclePredictor(params, graphs, len(cfg.lat), len(cfg.lon)), std, mean, dstd)
   t0 = time.perf_counter()
-  want = rollout.chunked_prediction(lambda rng, **kw: ref(**kw), None, inputs, template, forcings)
-  dt = time.perf_counter() - t0
-  traj = np.stack([stacked_rows(want, template, s, rows) for s in range(cfg.n_steps)]).astype(np.float32)
   os.makedirs(out_dir, exist_ok=True)
-  np.savez_compressed(os.path.join(out_dir, cfg.fixture), rows=rows, traj=traj,
-                      inputs_sha256=np.array(digest(params, inputs, forcings)),
-                      config=np.array([cfg.res, cfg.mesh, GNN_STEPS, cfg.n_steps]))
-  print(f"wrote {cfg.fixture}: traj {traj.shape}, oracle graphs {t_graphs:.0f} s, oracle rollout {dt:.0f} s")
+  sha = np.array(digest(params, inputs, forcings))
+  one_step = xarray.Dataset({k: template[k].isel(time=slice(0, 1)) for k in sorted(template.keys())})
+  traj = []
+  # chunk by chunk (= what chunked_prediction concatenates, utils/rollout.py:352-364): only the sampled
+  # rows of a lead time are kept (40 full 0.25 deg frames are 38 GB), and the fixture is rewritten after
+  # every step so that an interrupted run leaves a shorter, still valid trajectory (the test reads the
+  # number of lead times from the file).
+  for s, chunk in enumerate(rollout.chunked_prediction_generator(
+      lambda rng, **kw: ref(**kw), None, inputs, template, 1, forcings)):
+    traj.append(stacked_rows(rollout._to_host(chunk), one_step, 0, rows).astype(np.float32))
+    del chunk
+    np.savez_compressed(os.path.join(out_dir, cfg.fixture), rows=rows, traj=np.stack(traj), inputs_sha256=sha,
+                        config=np.array([cfg.res, cfg.mesh, GNN_STEPS, cfg.n_steps]))
+    print(f"step {s + 1}/{cfg.n_steps}: {time.perf_counter() - t0:.0f} s", flush=True)
+  dt = time.perf_counter() - t0
+  print(f"wrote {cfg.fixture}: traj {np.stack(traj).shape}, oracle graphs {t_graphs:.0f} s, oracle rollout {dt:.0f} s")
 
 
 if __name__ == "__main__":

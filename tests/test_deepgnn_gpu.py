@@ -91,6 +91,30 @@ def test_bipartite_no_edge_residuals_and_aggregate_normalization():
   assert rel(list(out.edges.values())[0].features.cpu().numpy(), want_e["mesh"]) <= 3e-6
 
 
+def test_batch_one_leaves_the_input_graph_untouched_and_bad_senders_raise():
+  """with batch == 1 `h[:, b].contiguous()` is a view of the caller's tensor and the in-place node
+  launches overwrote it -- the reference's DeepGNN never modifies its input (a second call must give the same)."""
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  x = G.inputs()
+  params = oparams.init_deep_gnn_params(G.LATENT, G.STEPS, {"mesh_nodes": 1}, ["mesh"], seed=G.SEED)
+  net = deep_gnn.DeepGNN(dense_kwargs=G.DENSE, num_message_passing_steps=G.STEPS, params=params, device=DEV)
+  g1 = graph({"mesh_nodes": x["h"][:, :1]}, x["senders"], x["receivers"], x["e"][:, :1])
+  h_before = g1.nodes["mesh_nodes"].features.clone()
+  e_before = list(g1.edges.values())[0].features.clone()
+  out_a = net(g1)
+  assert torch.equal(g1.nodes["mesh_nodes"].features, h_before)
+  assert torch.equal(list(g1.edges.values())[0].features, e_before)
+  out_b = net(g1)                                                   # same input, same answer
+  assert torch.equal(out_a.nodes["mesh_nodes"].features, out_b.nodes["mesh_nodes"].features)
+  gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gnn_deepgnn512.npz"))
+  assert rel(out_a.nodes["mesh_nodes"].features.cpu().numpy()[:, 0], gold["concat_nodes"][:, 0]) <= 3e-6
+  bad = x["senders"].copy()
+  bad[3] = x["n"]                                                   # one past the sender node set
+  with pytest.raises(ValueError, match="sender index"):
+    net(graph({"mesh_nodes": x["h"][:, :1]}, bad, x["receivers"], x["e"][:, :1]))
+
+
 def test_unsupported_configurations_fail_loudly():
   params = oparams.init_deep_gnn_params(512, 1, {"mesh_nodes": 1}, ["mesh"], seed=1)
   with pytest.raises(NotImplementedError, match="num_hidden_layers"):

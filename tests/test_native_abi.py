@@ -91,7 +91,10 @@ def test_build_checks_the_register_budget_of_the_hot_kernels():
             "x.inc:1:1: remark:     SGPRs Spill: 60 [-R]\n"
             "x.inc:1:1: remark:     VGPRs Spill: 56 [-R]\n"
             "x.inc:1:1: remark: Function Name: some_other_kernel [-R]\n"
-            "x.inc:1:1: remark:     ScratchSize [bytes/lane]: 4000 [-R]\n")
+            "x.inc:1:1: remark:     ScratchSize [bytes/lane]: 4000 [-R]\n"
+            "x.inc:1:1: remark: Function Name: _ZN12_GLOBAL__N_115rowmlpbf_kernelILb0ELi4EEEv14gc_rowmlp_desc [-R]\n"
+            "x.inc:1:1: remark:     ScratchSize [bytes/lane]: 244 [-R]\n"
+            "x.inc:1:1: remark:     Occupancy [waves/SIMD]: 2 [-R]\n")
   usage = nat.check_resources(remark.format(scratch=116, occ=2))
   sym = "_ZN12_GLOBAL__N_116rowmlp16h_kernelILi1ELi0EEEv14gc_rowmlp_desc"
   assert usage[sym] == dict(vgprs=256, scratch=116, occupancy=2, sgpr_spill=60, vgpr_spill=56)
@@ -99,3 +102,8 @@ def test_build_checks_the_register_budget_of_the_hot_kernels():
     nat.check_resources(remark.format(scratch=348, occ=2))
   with pytest.raises(RuntimeError, match="occupancy 1"):
     nat.check_resources(remark.format(scratch=0, occ=1))
+  # a gate with nothing to check must not pass: no remark for a kernel named in the limits
+  with pytest.raises(RuntimeError, match="no kernel-resource-usage remark"):
+    nat.check_resources("x.inc:1:1: remark: Function Name: some_other_kernel [-R]\n")
+  with pytest.raises(RuntimeError, match="no kernel-resource-usage remark"):
+    nat.check_resources("")

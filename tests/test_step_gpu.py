@@ -149,3 +149,42 @@ def test_step_with_injected_mesh2grid_faces_matches_oracle():
         f"vs the restated-rule graph {rel_rmse(differs, want):.2e}")
   assert err <= REL_RMSE_TOL
   assert rel_rmse(differs, want) > 10 * REL_RMSE_TOL           # the injection really changed the graph
+
+
+def test_f16x3_range_guard_raises_instead_of_wrong_numbers(small):
+  """the f16x3 split is exact only for |x| <= 65504; un-normalised fields (geopotential ~5e5)
+  must raise, never come back silently wrong.  Inside the range (values up to 6e4) the step still meets the budget;
+  f32 (the reference's arithmetic) takes anything."""
+  from graphcast_amd import _native as nat
+  rng = np.random.default_rng(5)
+  n_grid, c_in = small["graphs"]["n_grid"], small["c_in"]
+  x = rng.standard_normal((n_grid, 1, c_in)).astype(np.float32)
+  big = x.copy()
+  big[:, 0, 7] = np.abs(big[:, 0, 7]) * 1e4 + 5e5                 # one geopotential-scale channel
+  big[3, 0, c_in - 1] = -7e4                                       # ... and one value in the 32-column tail
+  model = small["model"]
+  engine = model._get_engine(c_in)
+  if small["precision"] == "f16x3" and engine.half:
+    model.forward_grid_node_features(torch.from_numpy(big).to("cuda:0"))
+    with pytest.raises(nat.GcastRangeError, match="65504"):
+      engine.check_range()
+    engine.check_range()                                           # the flag is cleared by the raise
+    only_tail = x.copy()
+    only_tail[3, 0, c_in - 1] = -7e4
+    model.forward_grid_node_features(torch.from_numpy(only_tail).to("cuda:0"))
+    with pytest.raises(nat.GcastRangeError):
+      engine.check_range()
+  elif small["precision"] == "f32":
+    y = model.forward_grid_node_features(torch.from_numpy(big).to("cuda:0")).cpu().numpy()
+    want = ogc.forward(small["params"], small["graphs"], big, steps=small["steps"], dtype=np.float64)
+    assert rel_rmse(y, want) <= REL_RMSE_TOL
+  if small["precision"] in ("f16x3", "f32"):
+    ok = x.copy()
+    ok[:, 0, 7] = np.abs(ok[:, 0, 7]) * 1e3 + 5e4                  # large but inside the exact range (< 65504)
+    ok[:, 0, 7] = np.minimum(ok[:, 0, 7], 6.5e4)
+    y = model.forward_grid_node_features(torch.from_numpy(ok).to("cuda:0")).cpu().numpy()
+    engine.check_range()
+    want = ogc.forward(small["params"], small["graphs"], ok, steps=small["steps"], dtype=np.float64)
+    err = rel_rmse(y, want)
+    print(f"in-range large inputs ({small['precision']}): rel-RMSE {err:.2e}")
+    assert err <= 1e-4
