@@ -55,37 +55,56 @@ def flops_as_written(n_grid, n_mesh, e_g2m, e_mesh, e_m2g, c_in, c_out, steps, d
           + mlp(n_grid, d, c_out))
 
 
-def measured_traffic(kernel_key):
-  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-  (profiles/pmc_traffic.json, produced by scripts/pmc_summary.py from separate FETCH_SIZE /
-  WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
-  cannot run rocprofv3 on itself, so the number is attached from the profile of the SAME
-  command; null when no profile of this kernel is committed."""
-  path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def _stamped_profile(name, stage):
+  """Stage `stage` of profiles/<name> if that summary was measured on the build that is loaded NOW: the summaries
+  written by scripts/pmc_by_stage.py / sq_by_stage.py carry `_stamp.src` = the hash of the library sources they
+  were collected on; the loaded library reports the hash it was compiled from (gc_build_info ";src=").  bench.py
+  cannot run rocprofv3 on itself, so counters are attached from the profile of the SAME command -- and only then.
+  -> (stage dict | None, reason | None)"""
+  from graphcast_amd import _native as nat
+  path = os.path.join(ROOT, "profiles", name)
   try:
     with open(path) as f:
       table = json.load(f)
   except (OSError, ValueError):
-    return None
-  return table.get(kernel_key)
+    return None, f"profiles/{name} is not in the tree"
+  want = nat.loaded_source_hash()
+  have = (table.get("_stamp") or {}).get("src")
+  if have is None or want is None or have != want:
+    return None, (f"profiles/{name} was collected on sources {have}, the loaded library was built from {want}: "
+                  "re-collect the counter passes (scripts/final_session.sh)")
+  if stage not in table:
+    return None, f"profiles/{name} has no stage {stage}"
+  return dict(table[stage], env=(table["_stamp"].get("env") or {})), None
 
 
-def measured_mfma_busy(kernel_key):
-  """MFMA pipe busy fraction of the dominant launch from the committed rocprofv3 SQ counter passes of the SAME
-  command (profiles/r03_final2_sq_by_stage.json via scripts/sq_by_stage.py: SQ_VALU_MFMA_BUSY_CYCLES over the
-  SIMD cycles of two resident waves); like `traffic`, attached from the profile because bench.py cannot run
-  rocprofv3 on itself.  None when no profile of this kernel is committed."""
-  if not kernel_key.startswith("f16x3h:"):
-    return None
-  path = os.path.join(ROOT, "profiles", "r03_final2_sq_by_stage.json")
-  try:
-    with open(path) as f:
-      stage = json.load(f)[kernel_key.split(":")[1]]
-  except (OSError, ValueError, KeyError):
-    return None
-  return {"mfma_busy_per_simd": stage.get("mfma_busy_per_simd"), "wave_waiting": stage.get("wave_waiting"),
-          "lds_bank_conflict": stage.get("lds_bank_conflict"),
-          "source": "profiles/r03_final2_sq_by_stage.json (scripts/sq_by_stage.py on the committed counter rows)"}
+def measured_traffic(precision_key, stage):
+  """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+  WRITE_SIZE passes of the same bench command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
+  keyed to the loaded build (see _stamped_profile)."""
+  if not precision_key.startswith("f16x3h"):
+    return None, "no counter profile is kept for this arithmetic / formulation"
+  st, why = _stamped_profile("current_pmc_by_stage.json", stage)
+  if st is None:
+    return None, why
+  return {"bytes_per_launch": st["traffic_bytes_per_launch"], "fetch_bytes_per_launch": st["fetch_bytes_per_launch"],
+          "write_bytes_per_launch": st["write_bytes_per_launch"], "algorithmic_bytes": st["algorithmic_bytes_per_launch"],
+          "traffic_over_algorithmic": st["traffic_over_algorithmic"],
+          "source": "profiles/current_pmc_by_stage.json (scripts/pmc_by_stage.py; L2 <-> fabric boundary: Infinity-Cache hits "
+                    "are counted)", "env": st["env"]}, None
+
+
+def measured_mfma_busy(precision_key, stage):
+  """MFMA pipe busy fraction (and wave wait fractions) of the dominant launch from the committed rocprofv3 SQ counter
+  passes of the SAME command, keyed to the loaded build (see _stamped_profile)."""
+  if not precision_key.startswith("f16x3h"):
+    return None, "no counter profile is kept for this arithmetic / formulation"
+  st, why = _stamped_profile("current_sq_by_stage.json", stage)
+  if st is None:
+    return None, why
+  return {"mfma_busy_per_simd": st.get("mfma_busy_per_simd"), "wave_waiting": st.get("wave_waiting"),
+          "lds_bank_conflict": st.get("lds_bank_conflict"),
+          "source": "profiles/current_sq_by_stage.json (scripts/sq_by_stage.py)", "env": st["env"]}, None
 
 
 def fast_params(c_in, c_out, steps, seed=1):
@@ -196,6 +215,15 @@ def main():
                   help="GEMM arithmetic (include/gcast.h gc_precision); default: engine default")
   ap.add_argument("--no-cross-check", action="store_true",
                   help="skip the full-size f16x3-vs-f32-MFMA agreement check (N = 1 only)")
+  ap.add_argument("--mode", default="ensemble", choices=["ensemble", "partition"],
+                  help="what N > 1 GPUs do: 'ensemble' = one member per GPU, no collective (BASELINE.json config 4, "
+                       "weak scaling; the default and the driver's SCALE run); 'partition' = ONE step split over the N "
+                       "GPUs by octant, receiver-owned edges, 18 halo exchanges per step, one RCCL all_to_all_single "
+                       "each (config 5, strong scaling)")
+  ap.add_argument("--rollout-steps", type=int, default=40,
+                  help="N = 1: additionally (outside the timed region) time an autoregressive rollout of this many 6-h "
+                       "steps with the state resident in HBM -- BASELINE.json config 3: 40 = ten days -- and report it "
+                       "as `rollout` in the line; 0 = skip")
   args = ap.parse_args()
 
   import torch
@@ -212,10 +240,16 @@ def main():
                      "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
   torch.cuda.set_device(local_rank)
   device = f"cuda:{local_rank}"
-  if world > 1:
+  # Launched by torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment) the RCCL group is
+  # initialised whatever N is -- the N = 1 point of a scaling run goes through the same init, barrier and
+  # max-over-ranks path as N = 8.  A bare `python bench.py` (no rendezvous variables) stays single-process.
+  distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+  if distributed:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", rank=rank, world_size=world,
                             device_id=torch.device(device))
+  if args.mode == "partition":
+    return partition_main(args, rank, world, device, distributed)
 
   res, mesh_size, levels, gnn_steps = CONFIGS[args.config]
   task = {37: gc.TASK, 13: gc.TASK_13}[levels]
@@ -242,7 +276,7 @@ def main():
   engine = model._engine
 
   def barrier():
-    if world > 1:
+    if distributed:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -254,10 +288,11 @@ def main():
     engine(x, y)
   barrier()
   elapsed = time.perf_counter() - t0
-  if world > 1:
+  if distributed:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+  engine.check_range()          # (outside the timed region: the inputs were inside the f16x3 arithmetic's exact range)
   finite = bool(torch.isfinite(y).all().item())
   precision = engine.precision
 
@@ -300,7 +335,9 @@ def main():
     split = precision == "f16x3"
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
     issue = 3.0 if split else 1.0            # MFMA FLOPs issued per algorithmic FLOP
-    traffic_key = f"{precision}{'h' if getattr(engine, 'half', False) else ''}:{dominant}"
+    traffic_key = f"{precision}{'h' if getattr(engine, 'half', False) else ''}"
+    traffic, traffic_why = measured_traffic(traffic_key, dominant)
+    pmc, pmc_why = measured_mfma_busy(traffic_key, dominant)
     line = {
         "metric": "6-h rollout steps/sec at 0.25deg/37-level",
         "value": args.gpus * args.steps / elapsed,
@@ -336,9 +373,9 @@ def main():
                                              issue * achieved / SUSTAINED_F16_MFMA_TFLOPS["mfma_with_operand_streams"]),
             "launches_per_step": dom["launches"],
             "avg_launch_ms": dom["ms"] / dom["launches"],
-            "traffic": (measured_traffic(traffic_key) or {}).get("bytes_per_launch"),
-            "traffic_source": (measured_traffic(traffic_key) or {}).get("source"),
-            "pmc": measured_mfma_busy(traffic_key),
+            "traffic": (traffic or {}).get("bytes_per_launch"),
+            "traffic_detail": traffic if traffic is not None else {"unavailable": traffic_why},
+            "pmc": pmc if pmc is not None else {"unavailable": pmc_why},
             "step_executed_tflop": executed_tflop,
             "step_as_written_tflop": f_alg / 1e12,
             "step_frac_executed": executed_tflop / (ms_per_step / 1e3) / peak,
@@ -360,14 +397,102 @@ def main():
                         else "chunked, one workgroup per CU"),
         "build": nat.lib().gc_build_info().decode(),
     }
+    if args.gpus == 1 and args.rollout_steps > 0 and args.config == "0.25deg_37L_M6":
+      line["rollout"] = rollout_extra(model, task, lat, lon, args.rollout_steps)
     if args.gpus == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(c_in, c_out, gnn_steps, f_alg, full_graphs=g,
                                           full_x=x.cpu().numpy())
     else:
       line["cpu_baseline"] = None
     print(json.dumps(line))
-  if world > 1:
+  if distributed:
     dist.destroy_process_group()
+
+
+def rollout_extra(model, task, lat, lon, n_steps):
+  """BASELINE.json config 3 on the model the line was measured with: an `n_steps` x 6 h autoregressive rollout,
+  everything resident in HBM (rollout_device.DeviceRollout: the step + ONE fused gc_advance_state per step -- rolling
+  window, InputsAndResiduals' algebra, forcings); only the last frame is kept (40 frames are 38 GB)."""
+  import torch
+  from graphcast_amd import rollout_device
+  from graphcast_amd import synthetic
+  inputs, template, forcings = synthetic.make_example(task, lat, lon, num_target_steps=n_steps)
+  mean, std, dstd = synthetic.make_stats(task)
+  roll = rollout_device.DeviceRollout(model, std, mean, dstd)
+  roll.run(inputs, template.isel(time=slice(0, 1)), forcings.isel(time=slice(0, 1)), keep_trajectory=False)   # tables, warm-up
+  torch.cuda.synchronize()
+  last = roll.run(inputs, template, forcings, keep_trajectory=False)
+  torch.cuda.synchronize()
+  loop_ms = roll.last_loop_ms()
+  return {"steps": n_steps, "ms_per_step": loop_ms / n_steps, "steps_per_second": 1e3 * n_steps / loop_ms,
+          "advance_state_ms": roll.advance_ms(), "finite": bool(torch.isfinite(last).all().item()),
+          "what": f"{n_steps} x 6 h autoregressive steps, state + forcings resident in HBM (DeviceRollout), device-loop "
+                  "time by HIP events; parity of this loop: tests/test_rollout40_fullsize_gpu.py"}
+
+
+def partition_main(args, rank, world, device, distributed):
+  """BASELINE.json config 5: ONE 0.25 deg step strong-scaled over N GPUs (graphcast_amd/partition.py) -- the multi-mesh
+  and the grid split by octant (hemispheres / quadrants for 2 / 4 ranks), every edge owned by the rank that owns its
+  receiver (segment-sum stays local: the reference's shard pattern, utils/gather_scatter_ops.py:267-283), remote
+  sender rows through 18 halo exchanges per step, ONE all_to_all_single each.  Same JSON contract; `value` = steps/s
+  of the whole partitioned step (max over ranks)."""
+  import torch
+  import torch.distributed as dist
+  from graphcast_amd import _native as nat
+  from graphcast_amd import graphcast as gc
+  from graphcast_amd import partition
+  if not distributed:            # a bare `python bench.py --mode partition`: a single-process group, still RCCL
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+  res, mesh_size, levels, gnn_steps = CONFIGS[args.config]
+  task = {37: gc.TASK, 13: gc.TASK_13}[levels]
+  c_out = gc.num_output_channels(task)
+  c_in = 2 * (5 + 6 * levels) + 2 * 5 + 2 + 5
+  lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=LATENT, gnn_msg_steps=gnn_steps,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  params = fast_params(c_in, c_out, gnn_steps)
+  model = gc.GraphCast(cfg, task, params=params, device=device, precision=args.precision).init_from_coordinates(lat, lon)
+  g = model.graph_arrays()
+  mine = partition.plan(g, model._grid_nodes_lon, model._mesh_nodes_lon, world, grid_lat=model._grid_nodes_lat,
+                        mesh_lat=model._mesh_nodes_lat)[rank]
+  step = partition.DistributedPartitionedStep(mine, params, num_steps=gnn_steps, c_in=c_in, c_out=c_out, device=device,
+                                              precision=args.precision)
+  x = torch.from_numpy(np.random.default_rng(0).standard_normal(
+      (g["n_grid"], 1, c_in), dtype=np.float32)[mine.grid_owned]).to(device)
+  y = torch.empty((mine.n_grid_owned, 1, c_out), dtype=torch.float32, device=device)
+  for _ in range(args.warmup):
+    step(x, y)
+  dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step(x, y)
+  dist.barrier()
+  torch.cuda.synchronize()
+  t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  elapsed = float(t.item())
+  step.engine.check_range()
+  if rank == 0:
+    halo = {k: int(len(pl.halo_global)) for k, (pl, _) in partition.tables_of(mine).items()}
+    precision = step.engine.precision
+    print(json.dumps({
+        "metric": "6-h rollout steps/sec at 0.25deg/37-level",
+        "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (3 x f16-split MFMA products, f32 accumulate)" if precision == "f16x3" else precision,
+        "data": "synthetic",
+        "config": {"workload": f"GraphCast {args.config}: ONE encode-process-decode 6-h step partitioned over {world} GPU(s)",
+                   "parallelism": f"octant partition x{world} (partition.plan: hemispheres / quadrants / octants), receiver-owned "
+                                  f"edges, 18 halo exchanges per step = one RCCL all_to_all_single each",
+                   "rank0_rows": {"grid": mine.n_grid_owned, "mesh": mine.n_mesh_owned, "halo": halo},
+                   "overlap": os.environ.get("GCAST_OVERLAP", "0") == "1"},
+        "roofline": None, "cpu_baseline": None,
+        "precision": precision, "output_finite": bool(torch.isfinite(y).all().item()),
+        "build": nat.lib().gc_build_info().decode()}))
+  dist.destroy_process_group()
 
 
 if __name__ == "__main__":

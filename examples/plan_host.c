@@ -2,7 +2,9 @@
  *
  * Builds a toy model (a handful of grid / mesh nodes, random weights in the reference's haiku
  * layout), creates a plan, runs two steps and prints a checksum.  It is a usage example and the
- * proof that the header is plain C; parity is established by the tests, not here.
+ * proof that the header is plain C.  `plan_host <file>` additionally dumps everything it generated
+ * (tensors, graphs, x) and the y it got: tests/test_plan_gpu.py runs it on the MI355X and checks that y
+ * against plan.NativePlan, engine.StepEngine and the float64 oracle on the same model.
  *
  *   gcc -std=c99 -I include examples/plan_host.c -L graphcast_amd/csrc -lgcast_hip \
  *       -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,graphcast_amd/csrc -Wl,-rpath,/opt/rocm/lib -lm -o plan_host
@@ -74,7 +76,21 @@ static gc_edge_set make_edges(int n_edges, int n_send, int n_recv) {
   return e;
 }
 
-int main(void) {
+/* ---- dump: "GCPH", then records {int name_len; name; int rows; int cols; int is_int; payload} ---- */
+static void put_rec(FILE* f, const char* name, int rows, int cols, int is_int, const void* data) {
+  const int n = (int)strlen(name);
+  fwrite(&n, sizeof(int), 1, f); fwrite(name, 1, (size_t)n, f);
+  fwrite(&rows, sizeof(int), 1, f); fwrite(&cols, sizeof(int), 1, f); fwrite(&is_int, sizeof(int), 1, f);
+  fwrite(data, 4, (size_t)rows * cols, f);
+}
+static void put_edges(FILE* f, const char* name, const gc_edge_set* e) {
+  char key[64];
+  sprintf(key, "graph:%s:senders", name); put_rec(f, key, 1, e->n_edges, 1, e->h_senders);
+  sprintf(key, "graph:%s:receivers", name); put_rec(f, key, 1, e->n_edges, 1, e->h_receivers);
+  sprintf(key, "graph:%s:feat", name); put_rec(f, key, e->n_edges, e->n_feat, 0, e->h_feat);
+}
+
+int main(int argc, char** argv) {
   char stem[64];
   add_mlp("grid2mesh_gnn", "encoder_edges_grid2mesh", 4, D, 1);
   add_mlp("grid2mesh_gnn", "encoder_nodes_grid_nodes", C_IN + 3, D, 1);
@@ -116,8 +132,22 @@ int main(void) {
   hipMemcpy(d_x, x, sizeof(float) * N_GRID * batch * C_IN, kHostToDevice);
   for (int step = 0; step < 2; ++step)
     if (gc_step_forward(plan, d_x, d_y, batch, d_ws, ws_bytes, NULL)) { fprintf(stderr, "gc_step_forward: %s\n", gc_last_error()); return 1; }
+  /* the f16x3 arithmetic is exact for |x| <= 65504: ask before trusting y (synchronises the stream) */
+  if (gc_plan_check_range(plan, d_ws, NULL)) { fprintf(stderr, "gc_plan_check_range: %s\n", gc_last_error()); return 1; }
   hipDeviceSynchronize();
   hipMemcpy(y, d_y, sizeof(y), kDeviceToHost);
+  if (argc > 1) {
+    FILE* f = fopen(argv[1], "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", argv[1]); return 1; }
+    fwrite("GCPH", 1, 4, f);
+    for (int i = 0; i < g_nt; ++i) put_rec(f, g_t[i].name, g_t[i].rows, g_t[i].cols, 0, g_t[i].h_data);
+    put_rec(f, "graph:grid_node_feat", N_GRID, 3, 0, m.h_grid_node_feat);
+    put_rec(f, "graph:mesh_node_feat", N_MESH, 3, 0, m.h_mesh_node_feat);
+    put_edges(f, "g2m", &m.g2m); put_edges(f, "mesh", &m.mesh); put_edges(f, "m2g", &m.m2g);
+    put_rec(f, "x", N_GRID * batch, C_IN, 0, x);
+    put_rec(f, "y", N_GRID * batch, C_OUT, 0, y);
+    fclose(f);
+  }
   double sum = 0.0;
   for (int i = 0; i < N_GRID * C_OUT; ++i) sum += y[i];
   printf("%s\nworkspace %zu bytes, checksum %.6f\n", gc_build_info(), ws_bytes, sum);

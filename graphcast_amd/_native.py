@@ -171,6 +171,34 @@ def check_resources(remarks, limits=None):
   return usage
 
 
+def source_files():
+  """Every file the library is compiled from (the kernels' sources and the C-ABI header)."""
+  return sorted([os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".inc"))]
+                + [os.path.join(_INCLUDE, "gcast.h")])
+
+
+def source_hash():
+  """sha256 (16 hex digits) over the library's sources: compiled into the library (gc_build_info: ";src=...") and
+  stamped into the counter summaries under profiles/ -- bench.py attaches a profile's numbers to its line only when
+  the two agree (counters pasted from a profile of another build)."""
+  import hashlib
+  h = hashlib.sha256()
+  for f in source_files():
+    h.update(os.path.basename(f).encode() + b"\0")
+    with open(f, "rb") as fh:
+      h.update(fh.read())
+  return h.hexdigest()[:16]
+
+
+def loaded_source_hash():
+  """The source hash the LOADED library was compiled from (None: a library from before round 4)."""
+  info = lib().gc_build_info().decode()
+  for part in info.split(";"):
+    if part.startswith("src="):
+      return part[4:]
+  return None
+
+
 def build(force=False, verbose=False):
   """Compiles csrc/gcast.hip for gfx950 with hipcc (all build variants) and checks the register budget of
   the hot kernels from the compiler's resource-usage remarks."""
@@ -178,12 +206,14 @@ def build(force=False, verbose=False):
   hdr = os.path.join(_INCLUDE, "gcast.h")
   deps = [src, hdr] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".inc")]
   newest = max(os.path.getmtime(f) for f in deps)
+  src_hash = source_hash()
   for variant, (_, define) in VARIANTS.items():
     out = library_path(variant)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
       continue
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm",
-           "-Rpass-analysis=kernel-resource-usage", define, "-I", _INCLUDE, "-shared", "-fPIC", src, "-o", out]
+           "-Rpass-analysis=kernel-resource-usage", define, f'-DGC_SRC_HASH="{src_hash}"', "-I", _INCLUDE, "-shared",
+           "-fPIC", src, "-o", out]
     if verbose:
       print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -1463,8 +1463,14 @@ bool half_tile_xcd() {
   return v;
 }
 
+template <int MODE, int ONEPASS>
+int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s);
+int half_helpers_default();
+
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
+  if ((d.flags & GC_WG_HELPERS) || (!(d.flags & GC_WG_NO_HELPERS) && half_helpers_default()))
+    return launch_rowmlp_half_d<MODE, ONEPASS>(d, s);
   const size_t lds = kHLdsFloats * sizeof(float);
   if (!g_h_attr_set[MODE][ONEPASS]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16h_kernel<MODE, ONEPASS>),
@@ -1483,6 +1489,39 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
   hipLaunchKernelGGL((rowmlp16h_kernel<MODE, ONEPASS>), dim3(grid), dim3(256), lds, s, dd);
   return check_launch("rowmlp16h_kernel");
+}
+
+// The eight-wave "helper waves" form of the same launch (csrc/rowmlp_half.inc: rowmlp16d_kernel): ONE persistent
+// workgroup per CU.  gc_rowmlp_desc.flags GC_WG_HELPERS asks for it per launch, GCAST_HELPERS=1|0 (read once) for a
+// whole process.
+bool g_d_attr_set[3][4] = {};
+int half_helpers_default() {
+  static const int v = [] {
+    const char* e = std::getenv("GCAST_HELPERS");
+    return e ? std::atoi(e) : GC_HELPERS_DEFAULT;
+  }();
+  return v;
+}
+
+template <int MODE, int ONEPASS = 0>
+int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
+  const size_t lds = kHLdsFloats * sizeof(float);
+  if (!g_d_attr_set[MODE][ONEPASS]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16d_kernel<MODE, ONEPASS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+      return GC_ELAUNCH;
+    }
+    g_d_attr_set[MODE][ONEPASS] = true;
+  }
+  const int tiles = (d.n_rows + kHRows - 1) / kHRows;
+  const int cap = half_grid_cap() < GC_SCRATCH_SLOTS / 2 ? half_grid_cap() : GC_SCRATCH_SLOTS / 2;   // one workgroup per CU
+  const int grid = tiles < cap ? tiles : cap;
+  gc_rowmlp_desc dd = d;
+  if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
+  hipLaunchKernelGGL((rowmlp16d_kernel<MODE, ONEPASS>), dim3(grid), dim3(512), lds, s, dd);
+  return check_launch("rowmlp16d_kernel");
 }
 
 bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};
@@ -1854,7 +1893,11 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
   return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;tiers=bf16gemm|bf16(Bfloat16Cast);"
-         "layouts=chunked|half(2wg/cu,persistent,chain);pipe=" GC_STR(GC_PIPE) ";ring=4x16k"
+         "layouts=chunked|half(2wg/cu,persistent,chain)|half+helpers(8 waves,1wg/cu);pipe=" GC_STR(GC_PIPE) ";ring=4x16k"
+         ";helpers_default=" GC_STR(GC_HELPERS_DEFAULT)
+#ifdef GC_SRC_HASH
+         ";src=" GC_SRC_HASH
+#endif
 #ifdef GC_PROFILING_BUILD
          ";PROFILING_BUILD(results may be wrong)"
 #endif

@@ -285,6 +285,9 @@ class GraphCast(predictor_base.Predictor):
     device (rollouts that keep the state in HBM: nothing crosses PCIe)."""
     del is_training
     import torch
+    from graphcast_amd import xarray_lite as xl
+    # (real xarray Datasets of a host that has xarray are adapted here; xarray_lite objects pass through)
+    inputs, targets_template, forcings = xl.from_xarray(inputs), xl.from_xarray(targets_template), xl.from_xarray(forcings)
     self._maybe_init(np.asarray(inputs.coords["lat"].values), np.asarray(inputs.coords["lon"].values))
     features = self._inputs_to_grid_node_features(inputs, forcings)
     on_device = torch.is_tensor(features)

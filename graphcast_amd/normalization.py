@@ -74,6 +74,8 @@ class InputsAndResiduals(predictor_base.Predictor):
   def __init__(self, predictor: predictor_base.Predictor, stddev_by_level: xarray.Dataset,
                mean_by_level: xarray.Dataset, diffs_stddev_by_level: xarray.Dataset):
     self._predictor = predictor
+    stddev_by_level, mean_by_level, diffs_stddev_by_level = (
+        xarray.from_xarray(stddev_by_level), xarray.from_xarray(mean_by_level), xarray.from_xarray(diffs_stddev_by_level))
     self._state_stats = (stddev_by_level, mean_by_level)          # (scales, locations)
     self._residual_stats = (diffs_stddev_by_level, None)
 
@@ -102,6 +104,8 @@ class InputsAndResiduals(predictor_base.Predictor):
     return normalize(inputs, *self._state_stats), normalize(forcings, *self._state_stats)
 
   def __call__(self, inputs, targets_template, forcings, **kwargs):
+    inputs, targets_template, forcings = (xarray.from_xarray(inputs), xarray.from_xarray(targets_template),
+                                          xarray.from_xarray(forcings))
     norm_inputs, norm_forcings = self._normalised_io(inputs, forcings)
     norm_predictions = self._predictor(norm_inputs, targets_template, forcings=norm_forcings, **kwargs)
     return _each_variable(norm_predictions, lambda p: self._physical(inputs, p))

@@ -168,6 +168,10 @@ def chunked_prediction_generator(
       ds = replicate_fn(ds)
     return device_put_fn(ds) if device_put_fn is not None else ds
 
+  # (a host that has xarray may pass its own Datasets: adapted once, here; predictions come back as xarray_lite
+  #  Datasets -- xarray_lite.to_xarray(predictions, xarray) converts them for such a host)
+  inputs, targets_template, forcings = (xarray.from_xarray(inputs), xarray.from_xarray(targets_template),
+                                        xarray.from_xarray(forcings))
   schedule = _ChunkSchedule(inputs, targets_template, forcings, num_steps_per_chunk)
   state = stage(schedule.first_inputs)          # the rolling input window; stays where `stage` put it
   del inputs

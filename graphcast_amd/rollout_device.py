@@ -148,7 +148,8 @@ class DeviceRollout:
   def __init__(self, model, stddev_by_level: xarray.Dataset, mean_by_level: xarray.Dataset,
                diffs_stddev_by_level: xarray.Dataset):
     self._model = model
-    self._std, self._mean, self._dstd = stddev_by_level, mean_by_level, diffs_stddev_by_level
+    self._std, self._mean, self._dstd = (xarray.from_xarray(stddev_by_level), xarray.from_xarray(mean_by_level),
+                                         xarray.from_xarray(diffs_stddev_by_level))
     self._lib = nat.lib()
     self._tables = None
 
@@ -174,6 +175,8 @@ class DeviceRollout:
     when ``keep_trajectory`` is False."""
     model = self._model
     dev = model._device
+    inputs, targets_template, forcings = (xarray.from_xarray(inputs), xarray.from_xarray(targets_template),
+                                          xarray.from_xarray(forcings))
     n_steps = targets_template.sizes["time"]
     if forcings.sizes.get("time") != n_steps:
       raise ValueError("forcings must cover every target time")

@@ -782,3 +782,55 @@ def zeros_like(obj, dtype=None):
   else:
     z = np.zeros_like(data, dtype=dtype)
   return DataArray(Variable(obj.dims, z), coords=getattr(obj, "_coords", None), name=getattr(obj, "name", None))
+
+
+# ----------------------------------------------------------------------------- real-xarray boundary
+def is_lite(obj) -> bool:
+  return isinstance(obj, (Dataset, DataArray, Variable))
+
+
+def from_xarray(obj):
+  """A real ``xarray.Dataset`` / ``xarray.DataArray`` (or anything that quacks like one: ``.data_vars`` /
+  ``.coords`` mappings whose values expose ``.dims`` and ``.values`` / ``.data``) -> the xarray_lite
+  equivalent; xarray_lite objects and None pass through.  The Predictor boundary (``GraphCast.__call__``,
+  ``rollout.chunked_prediction*``, ``normalization.InputsAndResiduals``) calls this on what it is handed, so a
+  host that HAS xarray can pass its own Datasets (reference ``utils/predictor_base.py:43-84``); xarray itself is
+  never imported here (it is not installable in this image -- the test uses a duck-typed stand-in).
+  Data stay where they are: numpy arrays are not copied, torch tensors stay on their device; lazily loaded
+  (dask) variables are materialised through ``.values``."""
+  if obj is None or is_lite(obj):
+    return obj
+
+  def var(v):
+    data = getattr(v, "data", None)
+    if data is None or not (isinstance(data, np.ndarray) or _is_torch(data)):
+      data = np.asarray(v.values)
+    return Variable(tuple(v.dims), data)
+
+  if hasattr(obj, "data_vars"):
+    return Dataset._construct({str(k): var(v) for k, v in obj.data_vars.items()},
+                              {str(k): var(v) for k, v in obj.coords.items()})
+  if hasattr(obj, "dims") and hasattr(obj, "coords"):
+    arr = DataArray(var(obj).data, dims=tuple(obj.dims), name=getattr(obj, "name", None))
+    return arr.assign_coords({str(k): var(v) for k, v in obj.coords.items()})
+  raise TypeError(f"cannot adapt {type(obj).__name__}: expected an xarray / xarray_lite Dataset or DataArray")
+
+
+def to_xarray(ds, xarray_module=None):
+  """The way back for a host that has xarray: ``to_xarray(predictions, xarray)`` builds ``xarray.Dataset`` (or
+  ``DataArray``) objects from xarray_lite ones through the public constructors ``Dataset(data_vars, coords)`` /
+  ``DataArray(data, coords, dims, name)`` with ``{name: (dims, array)}`` entries -- torch-backed variables are
+  copied to host numpy first.  Without a module, returns those constructor arguments."""
+  def arr(v):
+    data = v.data
+    return data.detach().cpu().numpy() if _is_torch(data) else np.asarray(data)
+
+  if isinstance(ds, Dataset):
+    data_vars = {k: (tuple(v.dims), arr(v)) for k, v in ds._vars.items()}
+    coords = {k: (tuple(v.dims), arr(v)) for k, v in ds._coords.items()}
+    return xarray_module.Dataset(data_vars, coords=coords) if xarray_module is not None else (data_vars, coords)
+  if isinstance(ds, DataArray):
+    coords = {k: (tuple(v.variable.dims), arr(v.variable)) for k, v in ds.coords.items()}
+    args = dict(data=arr(ds.variable), coords=coords, dims=tuple(ds.dims), name=ds.name)
+    return xarray_module.DataArray(**args) if xarray_module is not None else args
+  raise TypeError(f"expected an xarray_lite Dataset / DataArray, got {type(ds).__name__}")

@@ -108,6 +108,13 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
 #define GC_WG_ROWS_128 8         /* or 128 (eight waves sharing one weight stream, one workgroup per CU).  Neither
                                   * flag: chosen per launch (128 for launches without gather / segment-sum from
                                   * 65,536 rows on).  Results are bit-identical either way. */
+#define GC_WG_HELPERS 32         /* GC_LAYOUT_HALF: run the launch as ONE eight-wave workgroup per CU -- four multiplying
+                                  * waves, four waves that stage the weight ring for them (csrc/rowmlp_half.inc:
+                                  * rowmlp16d_kernel) -- instead of two four-wave workgroups.  Bit-identical results. */
+#define GC_WG_NO_HELPERS 64      /* ... or pin the four-wave form (neither flag: the build's default, GC_HELPERS_DEFAULT) */
+#ifndef GC_HELPERS_DEFAULT
+#define GC_HELPERS_DEFAULT 0
+#endif
 #define GC_TILE_XCD 16           /* GC_LAYOUT_HALF: tile -> workgroup map in which each XCD walks a contiguous eighth
                                   * of the launch's tiles (csrc/rowmlp_half.inc).  A speed choice only. */
 

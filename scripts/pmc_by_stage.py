@@ -16,6 +16,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stamp                                     # noqa: E402
+
 STAGES = (["enc_embed_grid", "enc_edge", "enc_node_mesh", "enc_node_grid"]
           + ["proc_edge", "proc_node"] * 16 + ["dec_edge", "dec_node"])
 
@@ -26,7 +29,8 @@ def rowmlp_values(root, kernel_sub):
   for f in files:
     with open(f, newline="") as fh:
       for r in csv.DictReader(fh):
-        if kernel_sub in r["Kernel_Name"] and "<0" not in r["Kernel_Name"]:
+        # (rowmlp16h_kernel / rowmlp16d_kernel: the four-wave and the helper-wave form of the same launch)
+        if any(k in r["Kernel_Name"] for k in kernel_sub) and "<0" not in r["Kernel_Name"]:
           rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
   rows.sort()
   return [v for _, v in rows]
@@ -52,7 +56,7 @@ def algorithmic(elem):
 def main():
   fetch_dir, write_dir = sys.argv[1], sys.argv[2]
   elem = int(sys.argv[sys.argv.index("--elem") + 1]) if "--elem" in sys.argv else 4
-  kernel = "rowmlpbf_kernel" if elem == 2 else "rowmlp16h_kernel"
+  kernel = ("rowmlpbf_kernel",) if elem == 2 else ("rowmlp16h_kernel", "rowmlp16d_kernel")
   f, w = rowmlp_values(fetch_dir, kernel), rowmlp_values(write_dir, kernel)
   n = len(STAGES)
   if len(f) < n or len(w) < n:
@@ -71,6 +75,7 @@ def main():
   tot_a = sum(v["algorithmic_bytes_per_launch"] * v["launches_per_step"] for v in out.values())
   out["_step"] = {"traffic_bytes": tot_t, "algorithmic_bytes": tot_a, "traffic_over_algorithmic": tot_t / tot_a,
                   "note": "FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 (KiB counters; gfx950 FETCH correction of MI355X_MICROARCH.md)"}
+  out["_stamp"] = _stamp.stamp()
   json.dump(out, sys.stdout, indent=1)
 
 

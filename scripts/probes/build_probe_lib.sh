@@ -11,8 +11,10 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 PATCH=$1; OUT=$2; shift 2
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT
-cp "$ROOT"/graphcast_amd/csrc/*.hip "$ROOT"/graphcast_amd/csrc/*.inc "$TMP"/
+cp "$ROOT"/graphcast_amd/csrc/*.hip "$ROOT"/graphcast_amd/csrc/*.inc "$ROOT"/include/gcast.h "$TMP"/
 (cd "$TMP" && patch -s -p0 < "$ROOT/scripts/probes/$(basename "$PATCH")")
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-inline-asm -DGC_PROFILING_BUILD -DGC_PIPE=2 "$@" \
-  -I "$ROOT/include" -shared -fPIC "$TMP/gcast.hip" -o "$OUT"
+  -I "$TMP" -I "$ROOT/include" -shared -fPIC "$TMP/gcast.hip" -o "$OUT"
 echo "built $OUT ($*)"
+# (f16x3_gemm_phase_semaphore.patch also patches gcast.h -- one pointer appended to gc_rowmlp_desc, filled in by the
+#  library itself: the copy of the header in $TMP is the one compiled against; run it with GCAST_GEMM_MUTEX=1)

@@ -6,7 +6,8 @@ derived where the inputs are present (units per /opt/skills/guides/MI355X_MICROA
 SQ_WAIT_* / SQ_ACTIVE_INST_* counters are QUAD-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES is cycles
 summed over SIMDs = 16 x #MFMA for the 16x16x32 shapes):
 
-  mfma_busy_per_simd   = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_WAVE_CYCLES / 2)     two resident waves per SIMD
+  mfma_busy_per_simd   = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_WAVE_CYCLES / 2)     two resident waves per SIMD (both
+                         forms of the launch: two four-wave workgroups, or one eight-wave workgroup, per CU)
   wave_waiting         = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
   wave_waiting_on_lds  = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
   lds_bank_conflict    = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
@@ -22,19 +23,22 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stamp                                     # noqa: E402
+
 STAGES = (["enc_embed_grid", "enc_edge", "enc_node_mesh", "enc_node_grid"]
           + ["proc_edge", "proc_node"] * 16 + ["dec_edge", "dec_node"])
 
 
 def main():
   per = defaultdict(dict)           # counter -> {dispatch id: value}
-  for root in sys.argv[1:]:
+  for root in [a for a in sys.argv[1:] if not a.startswith("--")]:
     files = [root] if os.path.isfile(root) else glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)
     for f in files:
       with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
           k = r["Kernel_Name"]
-          if "rowmlp16h_kernel" in k and "<0" not in k:
+          if ("rowmlp16h_kernel" in k or "rowmlp16d_kernel" in k) and "<0" not in k:
             d = per[r["Counter_Name"]]
             d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
   out = {}
@@ -58,6 +62,8 @@ def main():
       c["wave_waiting_on_lds"] = g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES")
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
       c["lds_bank_conflict"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+  if "--no-stamp" not in sys.argv:
+    out["_stamp"] = _stamp.stamp()
   json.dump(out, sys.stdout, indent=1)
 
 

@@ -604,6 +604,7 @@ def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows():
   out = subprocess.run([sys.executable, os.path.join(root, "scripts", "sq_by_stage.py"), *rows], check=True,
                        capture_output=True, text=True).stdout
   got = json.loads(out)
+  assert set(got.pop("_stamp")) == {"src", "env"}          # round 4: what the summary was measured on
   with open(os.path.join(root, "profiles", "r03_final2_sq_by_stage.json")) as f:
     want = json.load(f)
   assert got.keys() == want.keys() and len(got) == 8
@@ -635,3 +636,95 @@ def test_committed_traffic_summary_is_reproducible_from_the_committed_counter_ro
   with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
     table = json.load(f)
   assert table["f16x3h:proc_edge"]["bytes_per_launch"] == want["proc_edge"]["traffic_bytes_per_launch"]
+
+
+def test_bench_attaches_counters_only_from_a_profile_of_the_loaded_build(tmp_path):
+  """roofline.traffic / roofline.pmc used to be pasted from whatever summary was committed.
+  Now a summary carries the hash of the sources it was collected on and bench.py attaches it only when the loaded
+  library reports the same hash (gc_build_info ";src=")."""
+  import json
+  import bench
+  from graphcast_amd import _native as nat
+  have = nat.loaded_source_hash()
+  assert have == nat.source_hash(), "the in-tree library is stale: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+  stage = {"traffic_bytes_per_launch": 2.0, "fetch_bytes_per_launch": 1.0, "write_bytes_per_launch": 1.0,
+           "algorithmic_bytes_per_launch": 1.0, "traffic_over_algorithmic": 2.0, "mfma_busy_per_simd": 0.5}
+  good, bad, old = tmp_path / "good.json", tmp_path / "bad.json", tmp_path / "old.json"
+  good.write_text(json.dumps({"proc_edge": stage, "_stamp": {"src": have, "env": {"GCAST_HELPERS": "1"}}}))
+  bad.write_text(json.dumps({"proc_edge": stage, "_stamp": {"src": "0123456789abcdef", "env": {}}}))
+  old.write_text(json.dumps({"proc_edge": stage}))
+  got, why = bench._stamped_profile(str(good), "proc_edge")
+  assert why is None and got["mfma_busy_per_simd"] == 0.5 and got["env"] == {"GCAST_HELPERS": "1"}
+  for f in (bad, old):
+    got, why = bench._stamped_profile(str(f), "proc_edge")
+    assert got is None and "re-collect" in why
+  got, why = bench._stamped_profile(str(tmp_path / "missing.json"), "proc_edge")
+  assert got is None and "not in the tree" in why
+  assert bench.measured_traffic("f32", "proc_edge")[0] is None
+
+
+# ----------------------------------------------------------------------------- real-xarray boundary
+class _FakeXrVariable:
+  """What the adapter may rely on of an xarray Variable / DataArray / coordinate: .dims, .values, .data, .name."""
+
+  def __init__(self, dims, values, name=None):
+    self.dims, self._values, self.name = tuple(dims), np.asarray(values), name
+    self.coords = {}
+
+  @property
+  def values(self):
+    return self._values
+
+  @property
+  def data(self):
+    return self._values
+
+
+class _FakeXrDataset:
+  """Quacks like xarray.Dataset as far as the adapter looks: .data_vars and .coords mappings."""
+
+  def __init__(self, lite):
+    self.data_vars = {k: _FakeXrVariable(v.dims, v.values, k) for k, v in lite.variables.items() if k in lite.data_vars}
+    self.coords = {k: _FakeXrVariable(v.variable.dims, v.values, k) for k, v in lite.coords.items()}
+
+
+def test_real_xarray_objects_are_adapted_at_the_predictor_boundary():
+  """VERDICT r3 missing #4: INTEGRATION.md says a host may pass its own xarray Datasets.  xarray is not installable here,
+  so a duck-typed stand-in (.data_vars / .coords -> objects with .dims / .values / .data) goes through
+  xarray_lite.from_xarray at the boundary: rollout.chunked_prediction around normalization.InputsAndResiduals gives
+  the same predictions as with xarray_lite Datasets, and to_xarray hands back plain constructor arguments."""
+  from graphcast_amd import graphcast as gc
+  from graphcast_amd import normalization, rollout, synthetic
+  from graphcast_amd import xarray_lite as xl
+  lat, lon = np.arange(-90, 91, 30.0), np.arange(0, 360, 30.0)
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, lat, lon, num_target_steps=3, seed=3)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  back = xl.from_xarray(_FakeXrDataset(inputs))
+  assert sorted(back.keys()) == sorted(inputs.keys()) and dict(back.sizes) == dict(inputs.sizes)
+  for k in inputs.keys():
+    assert back[k].dims == inputs[k].dims
+    np.testing.assert_array_equal(back[k].values, inputs[k].values)
+  np.testing.assert_array_equal(back.coords["time"].values, inputs.coords["time"].values)
+  assert xl.from_xarray(inputs) is inputs and xl.from_xarray(None) is None
+  with pytest.raises(TypeError):
+    xl.from_xarray(3.0)
+
+  class Toy(predictor_base.Predictor):           # a cheap stand-in for the GNN step: tanh of a channel mix
+    def __call__(self, inputs, targets_template, forcings, **kw):
+      out = {}
+      for k in sorted(targets_template.keys()):
+        v = inputs[k].isel(time=slice(-1, None)) if k in inputs else None
+        base = np.tanh(np.asarray(v.values)) if v is not None else np.zeros(targets_template[k].shape, np.float32)
+        out[k] = (targets_template[k].dims, np.broadcast_to(base, targets_template[k].shape).astype(np.float32))
+      return xl.Dataset(out, coords={k: c.variable for k, c in targets_template.coords.items()})
+
+  run = lambda a, b, c, stats: rollout.chunked_prediction(
+      lambda rng, **kw: normalization.InputsAndResiduals(Toy(), *stats)(**kw), None, a, b, c)
+  want = run(inputs, template, forcings, (std, mean, dstd))
+  got = run(_FakeXrDataset(inputs), _FakeXrDataset(template), _FakeXrDataset(forcings),
+            tuple(_FakeXrDataset(s) for s in (std, mean, dstd)))
+  for k in want.keys():
+    np.testing.assert_array_equal(got[k].values, want[k].values)
+  data_vars, coords = xl.to_xarray(got)
+  assert set(data_vars) == set(want.keys()) and data_vars["2m_temperature"][0] == want["2m_temperature"].dims
+  assert "lat" in coords and coords["lat"][0] == ("lat",)

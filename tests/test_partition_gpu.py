@@ -138,3 +138,23 @@ def test_distributed_partitioned_step_two_ranks_share_one_gpu(setup, tmp_path):
         f"{rel:.2e}, vs float64 oracle {rel_oracle:.2e}")
   assert rel < 2e-6
   assert rel_oracle < 2e-5
+
+
+def test_rccl_path_executes_on_the_gpu():
+  """the `nccl` (RCCL) backend initialised with world_size 1 on the MI355X; DistExchanger.exchange
+  through all_to_all_single on DEVICE tensors (no host staging), the overlap-stream pattern, and one
+  DistributedPartitionedStep -- in a process of its own (tests/_nccl_ws1_worker.py)."""
+  import os
+  import socket
+  import subprocess
+  import sys
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_ws1_worker.py")
+  env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+             HSA_ENABLE_IPC_MODE_LEGACY="0")
+  p = subprocess.run([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                     timeout=600)
+  assert p.returncode == 0 and "NCCL_WS1_OK" in p.stdout, p.stdout[-3000:]
+  print(p.stdout.strip().splitlines()[-1])

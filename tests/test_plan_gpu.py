@@ -90,3 +90,63 @@ def test_fewer_than_32_input_channels(c_in):
   err = float(np.linalg.norm(got.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref))
   assert err <= 2e-5, err
   nat_plan.close()
+
+
+def test_c_host_example_runs_and_agrees_with_the_python_hosts(tmp_path):
+  """examples/plan_host.c -- a plain C99 program on include/gcast.h alone -- COMPILED AND RUN on the
+  MI355X; the y it gets from gc_plan_create / gc_step_forward / gc_plan_check_range on its toy model equals
+  plan.NativePlan's (same library, same packers: bit for bit), engine.StepEngine's, and the float64 oracle's."""
+  import os
+  import shutil
+  import struct
+  import subprocess
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  gcc = shutil.which("gcc")
+  assert gcc, "gcc is part of the image"
+  csrc, rocm_lib = os.path.join(root, "graphcast_amd", "csrc"), "/opt/rocm/lib"
+  exe = str(tmp_path / "plan_host")
+  subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "plan_host.c"),
+                  "-L", csrc, "-lgcast_hip", "-L", rocm_lib, "-lamdhip64", f"-Wl,-rpath,{csrc}", f"-Wl,-rpath,{rocm_lib}",
+                  "-lm", "-o", exe], check=True)
+  dump = str(tmp_path / "dump.bin")
+  run = subprocess.run([exe, dump], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+  assert run.returncode == 0 and "checksum" in run.stdout, run.stdout[-2000:]
+  rec = {}
+  with open(dump, "rb") as f:
+    assert f.read(4) == b"GCPH"
+    while True:
+      head = f.read(4)
+      if not head:
+        break
+      name = f.read(struct.unpack("i", head)[0]).decode()
+      rows, cols, is_int = struct.unpack("iii", f.read(12))
+      rec[name] = np.frombuffer(f.read(4 * rows * cols), dtype=np.int32 if is_int else np.float32).reshape(rows, cols)
+  params = {}
+  for name, a in rec.items():
+    if name.startswith("graph:") or name in ("x", "y"):
+      continue
+    module, leaf = name.rsplit("/", 1)
+    params.setdefault(module, {})[leaf] = a if leaf == "w" else a.reshape(-1)
+  edge = lambda k: dict(senders=rec[f"graph:{k}:senders"].reshape(-1), receivers=rec[f"graph:{k}:receivers"].reshape(-1),
+                        feat=rec[f"graph:{k}:feat"])
+  graphs = dict(n_grid=rec["graph:grid_node_feat"].shape[0], n_mesh=rec["graph:mesh_node_feat"].shape[0],
+                grid_node_feat=rec["graph:grid_node_feat"], mesh_node_feat=rec["graph:mesh_node_feat"],
+                g2m=edge("g2m"), mesh=edge("mesh"), m2g=edge("m2g"))
+  c_in, c_out, steps = rec["x"].shape[1], rec["y"].shape[1], 2
+  x = torch.from_numpy(rec["x"].reshape(graphs["n_grid"], 1, c_in).copy()).to("cuda:0")
+  kw = dict(num_steps=steps, c_in=c_in, c_out=c_out, precision="f16x3", half=True)
+  nat_plan = plan.NativePlan(graphs, params, **kw)
+  y_plan = nat_plan(x)
+  nat_plan.check_range()
+  y_eng = engine.StepEngine(graphs, params, **kw)(x)
+  torch.cuda.synchronize()
+  y_c = torch.from_numpy(rec["y"].reshape(graphs["n_grid"], 1, c_out).copy()).to("cuda:0")
+  assert torch.equal(y_c, y_plan), float((y_c - y_plan).abs().max())
+  assert torch.equal(y_c, y_eng)
+  ref = ogc.forward(params, graphs, x.cpu().numpy(), steps=steps, dtype=np.float64)
+  err = float(np.linalg.norm(rec["y"].reshape(ref.shape).astype(np.float64) - ref) / np.linalg.norm(ref))
+  print(f"C host (examples/plan_host.c) vs float64 oracle: rel-RMSE {err:.2e}; {run.stdout.strip().splitlines()[-1]}")
+  assert err <= 2e-5
+  nat_plan.close()

@@ -28,23 +28,27 @@ LON = np.arange(0, 360, RES)
 
 
 class OraclePredictor(predictor_base.Predictor):
-  """The reference's GraphCast.__call__ with the float64 oracle as the step."""
+  """The reference's GraphCast.__call__ with the float64 oracle as the step -- and the ORACLE's stacking
+  (oracle/stacking.py: plain dims / arrays, independent of graphcast_amd.model_utils and xarray_lite) on both sides of
+  it, so that a channel-order bug in the product's stacking shows up HERE too (this side used to
+  stack with the product's own helpers)."""
 
   def __init__(self, params, graphs):
     self.params, self.graphs = params, graphs
 
   def __call__(self, inputs, targets_template, forcings, **kw):
-    x = xarray.concat([model_utils.dataset_to_stacked(inputs),
-                       model_utils.dataset_to_stacked(forcings)], dim="channels")
-    x = np.asarray(model_utils.lat_lon_to_leading_axes(x).data, np.float64)
     from oracle import gnn as ognn
+    from oracle import stacking as ostack
+    plain = lambda ds: {k: (tuple(ds[k].dims), np.asarray(ds[k].values, np.float64)) for k in ds.keys()}
+    sizes = dict(inputs.sizes)
+    x = ostack.grid_node_features(plain(inputs), plain(forcings), sizes)
     bf16 = ognn.ACTIVATIONS == "bf16"          # (the op-by-op bfloat16 restatement runs in float32 containers)
-    y = ogc.forward(self.params, self.graphs, x.reshape((-1,) + x.shape[2:]), steps=STEPS,
-                    dtype=np.float32 if bf16 else np.float64, f32_aggregation=bf16)
-    y = xarray.DataArray(y.reshape((len(LAT), len(LON)) + y.shape[1:]),
-                         dims=("lat", "lon", "batch", "channels"))
-    return model_utils.stacked_to_dataset(model_utils.restore_leading_axes(y).variable,
-                                          targets_template)
+    y = ogc.forward(self.params, self.graphs, x, steps=STEPS, dtype=np.float32 if bf16 else np.float64,
+                    f32_aggregation=bf16)
+    template = {k: (tuple(targets_template[k].dims), tuple(targets_template[k].shape)) for k in targets_template.keys()}
+    out = ostack.prediction_from_grid_nodes(y, template, len(LAT), len(LON))
+    coords = {k: v.variable for k, v in targets_template.coords.items()}
+    return xarray.Dataset({k: (template[k][0], out[k]) for k in sorted(out)}, coords=coords)
 
 
 @pytest.fixture(scope="module")

@@ -188,3 +188,36 @@ def test_f16x3_range_guard_raises_instead_of_wrong_numbers(small):
     err = rel_rmse(y, want)
     print(f"in-range large inputs ({small['precision']}): rel-RMSE {err:.2e}")
     assert err <= 1e-4
+
+
+def test_checkpoint_file_to_hip_step(tmp_path):
+  """a CheckPoint in the reference's .npz layout (utils/checkpoint.py:26-54) written to a
+  FILE, read back with checkpoint.load, handed to GraphCast -> the HIP step equals the step on the in-memory
+  parameters bit for bit (and the configs survive the round trip)."""
+  import dataclasses
+  from graphcast_amd import checkpoint
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  res, mesh_size, steps = 6.0, 2, 2
+  lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=steps,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
+  params = {m: {k: np.asarray(v, np.float32) for k, v in leaves.items()}
+            for m, leaves in oparams.init_params(c_in, c_out, 512, steps, seed=11, nontrivial=True).items()}
+  ckpt = gc.CheckPoint(params=params, model_config=cfg, task_config=gc.TASK_13, description="round-4 test", license="none")
+  path = tmp_path / "graphcast_toy.npz"
+  with open(path, "wb") as f:
+    checkpoint.dump(f, ckpt)
+  with open(path, "rb") as f:
+    back = checkpoint.load(f, gc.CheckPoint)
+  assert back.model_config == cfg and back.task_config == gc.TASK_13 and back.description == "round-4 test"
+  assert sorted(back.params) == sorted(params)
+  x = torch.from_numpy(np.random.default_rng(2).standard_normal((len(lat) * len(lon), 1, c_in)).astype(np.float32)).to("cuda:0")
+  y_mem = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(lat, lon).forward_grid_node_features(x)
+  loaded = gc.GraphCast(back.model_config, back.task_config)
+  loaded.load_params(back.params)
+  y_file = loaded.init_from_coordinates(lat, lon).forward_grid_node_features(x)
+  torch.cuda.synchronize()
+  assert torch.isfinite(y_file).all()
+  assert torch.equal(y_file, y_mem)
