@@ -17,28 +17,48 @@ if [ "${DO_TESTS:-1}" = "1" ]; then
   [ $rc = 0 ] || { echo "GATE: GPU suite failed"; exit 1; }
 fi
 echo "== bench (driver's command)"; t0=$(date +%s); timeout 1200 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$? wall=$(( $(date +%s) - t0 )) s" | tee "$OUT/bench_wall.txt"; cut -c1-300 "$OUT/bench.json"
-echo "== bench, bf16 tier"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --precision bf16 > "$OUT/bench_bf16.json" 2>> "$OUT/bench.err"; echo "bench bf16 rc=$?"; cut -c1-200 "$OUT/bench_bf16.json"
+echo "== bench, bf16 tier"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 --precision bf16 > "$OUT/bench_bf16.json" 2>> "$OUT/bench.err"; echo "bench bf16 rc=$?"; cut -c1-200 "$OUT/bench_bf16.json"
 echo "== rocprofv3 kernel trace"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- \
-    python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "rocprof rc=$?"
+    python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-cross-check --rollout-steps 0 --op-timing-iters 1 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "rocprof rc=$?"
 python scripts/kernel_trace_by_stage.py "$OUT/prof" > "$OUT/kernel_trace_by_stage.csv" 2>> "$OUT/errors.txt"; head -c 600 "$OUT/kernel_trace_by_stage.csv"; echo
 for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do cp "$f" "$OUT/kernel_stats.csv"; done
 find "$OUT/prof" -type f -size +8M -delete
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 --pmc $C"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OLDPWD/$OUT/pmc_$C" -o pmc -- \
-      python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/pmc_$C.json" 2> "$OLDPWD/$OUT/pmc_$C.err"); echo "pmc $C rc=$?"
+      python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --rollout-steps 0 --op-timing-iters 1 > "$OLDPWD/$OUT/pmc_$C.json" 2> "$OLDPWD/$OUT/pmc_$C.err"); echo "pmc $C rc=$?"
 done
-python scripts/pmc_by_stage.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" > "$OUT/pmc_by_stage.json" 2>> "$OUT/errors.txt"; head -c 400 "$OUT/pmc_by_stage.json"; echo
+# (the row-MLP launches' counter rows, kept small enough to commit: the per-stage summaries are reproducible from them)
+rows() { python - "$1" "$2" <<'PY'
+import csv, glob, os, sys
+src, dst = sys.argv[1], sys.argv[2]
+out = None
+for f in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
+  with open(f, newline="") as fh:
+    r = csv.DictReader(fh)
+    for row in r:
+      if "rowmlp16" in row["Kernel_Name"]:
+        if out is None:
+          out = csv.DictWriter(open(dst, "w", newline=""), fieldnames=r.fieldnames); out.writeheader()
+        out.writerow(row)
+PY
+}
+for C in FETCH_SIZE WRITE_SIZE; do rows "$OUT/pmc_$C" "$OUT/pmc_${C}_rowmlp_launches.csv"; done
+python scripts/pmc_by_stage.py "$OUT/pmc_FETCH_SIZE_rowmlp_launches.csv" "$OUT/pmc_WRITE_SIZE_rowmlp_launches.csv" > "$OUT/pmc_by_stage.json" 2>> "$OUT/errors.txt"; head -c 400 "$OUT/pmc_by_stage.json"; echo
+cp "$OUT/pmc_by_stage.json" "$OUT/current_pmc_by_stage.json"      # -> profiles/current_pmc_by_stage.json (bench.py: roofline.traffic)
 if [ "${DO_SQ:-1}" = "1" ]; then
   i=0
   for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_ADDR_CONFLICT"; do
     i=$((i + 1))
     echo "== rocprofv3 --pmc (SQ set $i)"
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OLDPWD/$OUT/pmc_sq$i" -o pmc -- \
-        python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --op-timing-iters 1 > "$OLDPWD/$OUT/pmc_sq$i.json" 2> "$OLDPWD/$OUT/pmc_sq$i.err"); echo "pmc sq$i rc=$?"
+        python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --rollout-steps 0 --op-timing-iters 1 > "$OLDPWD/$OUT/pmc_sq$i.json" 2> "$OLDPWD/$OUT/pmc_sq$i.err"); echo "pmc sq$i rc=$?"
   done
-  python scripts/sq_by_stage.py "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "$OUT/sq_by_stage.json" 2>> "$OUT/errors.txt"; python -c "
-import json; j=json.load(open('$OUT/sq_by_stage.json')); print({k: {m: round(v[m], 3) for m in ('mfma_busy_per_simd', 'wave_waiting', 'wave_waiting_on_lds', 'lds_bank_conflict') if m in v} for k, v in j.items()})"
+  for i in 1 2; do rows "$OUT/pmc_sq$i" "$OUT/pmc_sq${i}_rowmlp_launches.csv"; done
+  python scripts/sq_by_stage.py "$OUT/pmc_sq1_rowmlp_launches.csv" "$OUT/pmc_sq2_rowmlp_launches.csv" > "$OUT/sq_by_stage.json" 2>> "$OUT/errors.txt"
+  cp "$OUT/sq_by_stage.json" "$OUT/current_sq_by_stage.json"      # -> profiles/current_sq_by_stage.json (bench.py: roofline.pmc)
+  python -c "
+import json; j=json.load(open('$OUT/sq_by_stage.json')); print({k: {m: round(v[m], 3) for m in ('mfma_busy_per_simd', 'wave_waiting', 'wave_waiting_on_lds', 'lds_bank_conflict') if m in v} for k, v in j.items() if not k.startswith('_')})"
 fi
 find "$OUT" -type f -size +8M -delete

@@ -23,7 +23,7 @@ PY
 }
 case "$MODE" in
   bench-ab)
-    ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-cross-check"
+    ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0"
     if [[ " $* " == *" -- "* ]]; then ARGS=""; while [ "$1" != "--" ]; do ARGS="$ARGS $1"; shift; done; shift; fi
     i=0
     for ENVS in "$@"; do

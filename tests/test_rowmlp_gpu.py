@@ -311,6 +311,14 @@ def test_edge_block_with_segment_sum(dev, case):
   assert torch.equal(first, agg)
   if not _HALF:
     return
+  # round 4: the helper-wave form (GC_WG_HELPERS: four multiplying + four staging waves, one workgroup per CU)
+  # runs the segment-sum's barriers with eight waves -- the same bits, rows and aggregate
+  first_out = out.clone()
+  d.flags = nat.WG_HELPERS
+  agg.fill_(float("nan")); out.zero_()
+  pipeline()
+  assert torch.equal(first, agg) and torch.equal(first_out, out)
+  d.flags = 0
   # ---- the ONE-PASS formulation of the same launch (GC_W2_NATURAL: no layer-1 GEMM, so every K chunk's
   #      hidden columns are formed on the fly from the addend rows; W2 in the natural K order; no scratch),
   #      with three addend sources and with two (the encoder edge update has no receiver term)
@@ -319,9 +327,14 @@ def test_edge_block_with_segment_sum(dev, case):
   w2n_img.scale = sc2
   w2n = up(w2n_img, dev)
   for with_g1 in (True, False):
-    d.w2p, d.flags, d.scratch = w2n.data_ptr(), nat.W2_NATURAL, None
+    d.w2p, d.scratch = w2n.data_ptr(), None
     if not with_g1:
       d.g1, d.idx1 = None, None
+    d.flags = nat.W2_NATURAL | nat.WG_HELPERS               # (first in the helper-wave form: must give the same bits)
+    agg.fill_(float("nan")); out.zero_()
+    pipeline()
+    helper_bits = (agg.clone(), out.clone())
+    d.flags = nat.W2_NATURAL
     agg.fill_(float("nan"))
     out.zero_()
     pipeline()
@@ -335,6 +348,7 @@ def test_edge_block_with_segment_sum(dev, case):
     again = agg.clone()
     pipeline()
     assert torch.equal(again, agg)
+    assert torch.equal(helper_bits[0], agg) and torch.equal(helper_bits[1], out)
 
 
 @pytest.mark.parametrize("n_rows,n2,batch", [(64, 227, 1), (500, 83, 2), (70, 240, 1)])
@@ -576,6 +590,14 @@ def test_half_persistent_loop_revisits_scratch_slots(dev):
   first = (out.clone(), y.clone())
   run(d)                                              # bitwise repeatable (no atomics, fixed tile -> slot map)
   assert torch.equal(first[0], out) and torch.equal(first[1], y)
+  # round 4: the same launch as ONE eight-wave workgroup per CU (four multiplying + four staging waves,
+  # GC_WG_HELPERS) and with the XCD-contiguous tile map (GC_TILE_XCD) -- speed choices: the same bits
+  for flags in (nat.WG_HELPERS, nat.TILE_MAP_XCD, nat.WG_HELPERS | nat.TILE_MAP_XCD):
+    out.zero_(); y.zero_()
+    d.flags = flags
+    run(d)
+    assert torch.equal(first[0], out) and torch.equal(first[1], y), flags
+  d.flags = nat.WG_NO_HELPERS
   assert_close(out.cpu().numpy(), res.astype(np.float64) + _mlp_ln_want(p), "rows over many tiles per slot")
   h32 = out.cpu().numpy().astype(np.float64)
   want = ognn.swish(h32 @ ws.astype(np.float64)) @ wo.astype(np.float64) + bo[:n_out]
