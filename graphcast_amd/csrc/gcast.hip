@@ -1505,7 +1505,7 @@ int half_helpers_default() {
 
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
-  const size_t lds = kHLdsFloats * sizeof(float);
+  const size_t lds = (kHLdsFloats + kHSlotFloats) * sizeof(float);     // + the parked accumulators (LDS, not the scratch slots)
   if (!g_d_attr_set[MODE][ONEPASS]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16d_kernel<MODE, ONEPASS>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -37,6 +37,7 @@ D = packing.LATENT
 # GCAST_PRECISION.
 DEFAULT_PRECISION = "f16x3"
 DEFAULT_HALF = "1"
+DEFAULT_HELPERS_MIN_ROWS = "65536"     # = GC_HELPERS_MIN_ROWS_DEFAULT (include/gcast.h); see StepEngine.helpers_min_rows
 
 # stage tags reported by gc_time_program / used by bench.py
 TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, enc_node_grid=5,
@@ -182,6 +183,9 @@ class StepEngine:
                        if self.half and self.prec == nat.PREC_F16X3 else None)
     # chained Linear layers + in-place grid input (only the half-N kernels have them); GCAST_FUSE=0
     # keeps one launch per reference layer group for A/B runs
+    # GCAST_HELPERS_MIN_ROWS=<n>: launches without gather / segment-sum from n rows on run in the helper-wave form
+    # (0 = never; DESIGN.md section 9.7: the grid-sized node launches are 3-5 % faster in it, profiles/r04_s7_*)
+    self.helpers_min_rows = int(os.environ.get("GCAST_HELPERS_MIN_ROWS", DEFAULT_HELPERS_MIN_ROWS))
     self.onepass = os.environ.get("GCAST_ONEPASS", "1") == "1"     # (0: the two-pass launches everywhere, for A/B runs)
     self.fuse = self.half and (os.environ.get("GCAST_FUSE", "1") == "1" or self.prec == nat.PREC_BF16)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
@@ -255,6 +259,11 @@ class StepEngine:
         and mode == nat.MODE_MLP_LN and k0 + k1 == 0 and d is not None and g0 is not None and not chain):
       # an edge update whose first layer was folded into addends: ONE pass (csrc/rowmlp_half.inc ONEPASS)
       ds.w2p, ds.flags = w2_natural.data_ptr(), ds.flags | nat.W2_NATURAL
+    if (self.helpers_min_rows and n_rows >= self.helpers_min_rows and self.half and self.prec == nat.PREC_F16X3
+        and g0 is None and edges is None):
+      # the big node-side launches (no gather, no segment-sum) in the eight-wave form: four multiplying + four
+      # weight-staging waves, parked accumulators in LDS (csrc/rowmlp_half.inc: rowmlp16d_kernel); same bits
+      ds.flags |= nat.WG_HELPERS
     if ln is not None:
       ds.ln_scale, ds.ln_offset = nat.ptr(ln[0]), nat.ptr(ln[1])
     ds.res, ds.ldres = nat.ptr(res), (res.shape[1] if res is not None else 0)

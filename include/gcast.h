@@ -115,6 +115,8 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
 #ifndef GC_HELPERS_DEFAULT
 #define GC_HELPERS_DEFAULT 0
 #endif
+#define GC_HELPERS_MIN_ROWS_DEFAULT 65536   /* the plan API / engine.StepEngine ask for GC_WG_HELPERS on launches without
+                                             * gather / segment-sum from this many rows on (0: never) */
 #define GC_TILE_XCD 16           /* GC_LAYOUT_HALF: tile -> workgroup map in which each XCD walks a contiguous eighth
                                   * of the launch's tiles (csrc/rowmlp_half.inc).  A speed choice only. */
 
