@@ -392,7 +392,10 @@ def main():
         "stages_ms": {k: round(v["ms"], 3) for k, v in sorted(per_stage.items())},
         "setup_seconds": round(t_setup, 1),
         "output_finite": finite,
-        "formulation": ("half-N kernels, two persistent workgroups per CU, chained layers" if getattr(engine, "fuse", False)
+        "formulation": (("half-N kernels, two persistent four-wave workgroups per CU, chained layers"
+                         + (f"; launches without gather / segment-sum from {engine.helpers_min_rows} rows on as ONE eight-wave "
+                            "workgroup per CU (four multiplying + four weight-staging waves)"
+                            if getattr(engine, "helpers_min_rows", 0) else "")) if getattr(engine, "fuse", False)
                         else "half-N kernels, two persistent workgroups per CU" if getattr(engine, "half", False)
                         else "chunked, one workgroup per CU"),
         "build": nat.lib().gc_build_info().decode(),
