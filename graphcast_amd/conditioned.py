@@ -65,6 +65,10 @@ class ConditionedEncoderDecoder(engine.StepEngine):
     import os
     self.half = (os.environ.get("GCAST_HALF", engine.DEFAULT_HALF) == "1") and self.prec == nat.PREC_F16X3
     self.scratch = None
+    # latents come from the caller: every launch that reads rows carries the f16x3 range flag (engine.StepEngine.check_range)
+    self.check_all_rows = True
+    self.range_flag = (torch.zeros((1,), dtype=torch.int32, device=self.dev)
+                       if self.half and self.prec == nat.PREC_F16X3 else None)
     self.onepass = False       # (its launches carry per-batch LayerNorm vectors through the two-pass kernels)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     self.c_grid, self.c_mesh, self.c_cond, self.c_out = c_grid, c_mesh, c_cond, c_out
@@ -215,6 +219,7 @@ class ConditionedEncoderDecoder(engine.StepEngine):
                     out_ptr=lat_grid.data_ptr() + 4 * b * D, ldo=batch * D)
       ops.append(self._op_mlp("enc_node_grid", d))
       self._run(ops)
+    self.check_range()
     return lat_mesh, lat_grid
 
   # ---------------------------------------------------------------- decoder
@@ -256,6 +261,7 @@ class ConditionedEncoderDecoder(engine.StepEngine):
           nat.MODE_MLP_OUT, ng, a0=self.h_dec, k0=D, w1p=m.w1, b1=m.b1, w2p=m.w2, b2=m.b2,
           n2=self.c_out, out_ptr=y.data_ptr() + 4 * b * self.c_out, ldo=batch * self.c_out)))
       self._run(ops)
+    self.check_range()
     return y
 
   # the GraphCast step API of the base class does not apply here

@@ -86,6 +86,10 @@ class DeepGNN(engine.StepEngine):
     self.precision, self.prec = precision, nat.PRECISIONS[precision]
     self.half = self.prec == nat.PREC_F16X3
     self.onepass, self.scratch, self._keep = False, None, []
+    # latents come from the caller: every launch that reads rows carries the f16x3 range flag (engine.StepEngine.check_range)
+    self.check_all_rows = True
+    self.range_flag = (torch.zeros((1,), dtype=torch.int32, device=self.dev)
+                       if self.half and self.prec == nat.PREC_F16X3 else None)
     self._mlps = None
     self._graphs = {}
 
@@ -206,6 +210,7 @@ class DeepGNN(engine.StepEngine):
       if not same:
         out_send[:, b] = hs
       out_e[:, b] = e.index_select(0, edges.rows_of_edge)
+    self.check_range()           # (f16x3: latents beyond +-65504 raise instead of coming back wrong)
     nodes = {recv_set: input_graph.nodes[recv_set]._replace(features=out_recv)}
     if not same:
       nodes[send_set] = input_graph.nodes[send_set]._replace(features=out_send)

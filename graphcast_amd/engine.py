@@ -160,6 +160,12 @@ def _chained(mlp: _Mlp, block=None):
 class StepEngine:
   """x [N_grid, B, C_in] fp32 (device) -> y [N_grid, B, C_out] fp32 (device)."""
 
+  # defaults for the classes that reuse this one's launch helpers without running its constructor
+  # (deep_gnn.DeepGNN, conditioned.ConditionedEncoderDecoder)
+  helpers_min_rows = 0
+  range_flag = None
+  check_all_rows = False        # True: EVERY launch with layer-1 rows carries the range flag (their latents are external)
+
   def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
                device="cuda:0", precision: Optional[str] = None, half: Optional[bool] = None,
                fold_only: bool = False):
@@ -228,7 +234,7 @@ class StepEngine:
             ln=None, res=None, out=None, ldo=None, out_ptr=None, edges: Optional[_Edges] = None,
             agg=None, chain=(), rows_f32=False, w2_natural=None, check_range=False):
     ds = nat.RowMlpDesc()
-    if check_range and self.range_flag is not None:
+    if (check_range or (self.check_all_rows and a0 is not None)) and self.range_flag is not None:
       ds.range_flag = self.range_flag.data_ptr()
     ds.flags = nat.ROWS_F32 if (rows_f32 and self.prec == nat.PREC_BF16) else 0
     ds.mode, ds.n_rows, ds.prec = mode, n_rows, self.prec

@@ -48,7 +48,7 @@ class NativePlan:
       import os
       from graphcast_amd import engine
       half = os.environ.get("GCAST_HALF", engine.DEFAULT_HALF) == "1"
-    self.half = bool(half) and precision == "f16x3"
+    self.half = (bool(half) and precision == "f16x3") or precision == "bf16"     # (the Bfloat16Cast tier exists in this formulation only)
     keep = []
 
     def edge_set(g):

@@ -368,8 +368,9 @@ typedef struct gc_model_desc {
   const float* h_mesh_node_feat;   /* [n_mesh, n_struct] */
   gc_edge_set g2m, mesh, m2g;      /* grid->mesh, mesh->mesh, mesh->grid */
   int layout;                /* enum gc_weight_layout of the launches: GC_LAYOUT_CHUNKED, or
-                                GC_LAYOUT_HALF (GC_PREC_F16X3 only; the workspace then includes the
-                                launches' scratch rows) */
+                                GC_LAYOUT_HALF (GC_PREC_F16X3: the workspace then includes the launches' scratch
+                                rows; GC_PREC_BF16, the Bfloat16Cast tier, exists in this formulation only:
+                                bfloat16 workspace rows, constants folded by the fp32-grade kernels at creation) */
 } gc_model_desc;
 
 typedef struct gc_tensor_desc {

@@ -27,9 +27,11 @@ def case():
   return dict(graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x3h", "f32", "bf16gemm"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3h", "f32", "bf16gemm", "bf16"])
 @pytest.mark.parametrize("batch", [1, 2])
 def test_native_plan_equals_python_plan_bit_for_bit(case, precision, batch):
+  # "bf16" (round 4): the Bfloat16Cast tier behind gc_plan_create / gc_step_forward -- C++ packers, the folded constants
+  # rounded once to bfloat16 in pi order, bfloat16 workspace rows: the same bits as engine.StepEngine(precision="bf16")
   # "f16x3h": f16x3 arithmetic, every launch in the half-N formulation (GC_LAYOUT_HALF)
   half = precision == "f16x3h"
   precision = "f16x3" if half else precision
@@ -46,7 +48,7 @@ def test_native_plan_equals_python_plan_bit_for_bit(case, precision, batch):
   again = nat_plan(x)                         # workspace reuse, determinism
   torch.cuda.synchronize()
   assert torch.equal(again, got)
-  if precision != "bf16gemm" and batch == 1:
+  if precision not in ("bf16gemm", "bf16") and batch == 1:
     ref = ogc.forward(case["params"], case["graphs"], x.cpu().numpy(), steps=case["steps"], dtype=np.float64)
     err = float(np.linalg.norm(got.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref))
     print(f"native plan vs float64 oracle ({precision}): rel-RMSE {err:.2e}")
