@@ -5,7 +5,7 @@ so a launch is identified by its POSITION in a step (see scripts/pmc_by_stage.py
 end with whole steps of 38 launches -- embed_grid, enc_edge, enc_node_mesh, enc_node_grid, 16 x (proc_edge,
 proc_node), dec_edge, dec_node.  All whole steps at the end of the trace are averaged.
 
-    python scripts/kernel_trace_by_stage.py gpurun_out/<run>/prof [--kernel rowmlp16h_kernel] > profiles/<name>.csv
+    python scripts/kernel_trace_by_stage.py gpurun_out/<run>/prof [--kernel rowmlp16] > profiles/<name>.csv
 """
 import csv
 import glob
@@ -18,14 +18,17 @@ STAGES = (["enc_embed_grid", "enc_edge", "enc_node_mesh", "enc_node_grid"]
 
 def main():
   root = sys.argv[1]
-  kernel = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "rowmlp16h_kernel"
+  # (default: both forms of the half-N launch -- rowmlp16h_kernel = two four-wave workgroups per CU, rowmlp16d_kernel =
+  #  one eight-wave workgroup with weight-staging waves; they interleave within a step)
+  kernel = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "rowmlp16"
   rows = []
   for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
     with open(f, newline="") as fh:
       for r in csv.DictReader(fh):
         if kernel in r["Kernel_Name"] and "<0" not in r["Kernel_Name"] and "ILi0E" not in r["Kernel_Name"]:
           rows.append((int(r["Dispatch_Id"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                       r["VGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"], r["Grid_Size_X"]))
+                       r["VGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"], r["Grid_Size_X"],
+                       "rowmlp16d" if "rowmlp16d" in r["Kernel_Name"] else "rowmlp16h"))
   rows.sort()
   n = len(STAGES)
   steps = len(rows) // n
@@ -35,7 +38,7 @@ def main():
   tail = rows[-steps * n:]
   w = csv.writer(sys.stdout)
   w.writerow(["stage", "launches_per_step", "steps_averaged", "mean_us_per_launch", "min_us", "max_us", "total_us_per_step",
-              "vgpr", "scratch_bytes", "lds_bytes", "grid_x"])
+              "vgpr", "scratch_bytes", "lds_bytes", "grid_x", "kernel"])
   total = 0.0
   for name in dict.fromkeys(STAGES):
     idx = [k for k, s in enumerate(STAGES) if s == name]
@@ -44,8 +47,8 @@ def main():
     per_step = sum(v) / steps
     total += per_step
     w.writerow([name, len(idx), steps, f"{sum(v) / len(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}", f"{per_step:.1f}",
-                meta[2], meta[3], meta[4], meta[5]])
-  w.writerow(["_all_row_mlp_launches", n, steps, "", "", "", f"{total:.1f}", "", "", "", ""])
+                meta[2], meta[3], meta[4], meta[5], meta[6]])
+  w.writerow(["_all_row_mlp_launches", n, steps, "", "", "", f"{total:.1f}", "", "", "", "", ""])
 
 
 if __name__ == "__main__":

@@ -592,21 +592,24 @@ def test_arithmetic_aligns_on_level_labels_like_the_reference_normalisation():
     rollout_device._stat(mean, "temperature", 501, 0.0)
 
 
-def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows():
-  """profiles/r03_final2_sq_by_stage.json (MFMA pipe busy per stage) is what
-  scripts/sq_by_stage.py computes from the committed rocprofv3 counter rows of the same session."""
+@pytest.mark.parametrize("tag", ["r03_final2", "r04_final"])
+def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows(tag):
+  """profiles/<tag>_sq_by_stage.json (MFMA pipe busy per stage) is what
+  scripts/sq_by_stage.py computes from the committed rocprofv3 counter rows of the same session (r04: the launches
+  of BOTH forms of the half-N kernel, rowmlp16h_kernel and rowmlp16d_kernel, in dispatch order)."""
   import json
   import os
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  rows = [os.path.join(root, "profiles", f"r03_final2_pmc_sq{i}_rowmlp_launches.csv") for i in (1, 2)]
+  rows = [os.path.join(root, "profiles", f"{tag}_pmc_sq{i}_rowmlp_launches.csv") for i in (1, 2)]
   out = subprocess.run([sys.executable, os.path.join(root, "scripts", "sq_by_stage.py"), *rows], check=True,
                        capture_output=True, text=True).stdout
   got = json.loads(out)
   assert set(got.pop("_stamp")) == {"src", "env"}          # round 4: what the summary was measured on
-  with open(os.path.join(root, "profiles", "r03_final2_sq_by_stage.json")) as f:
+  with open(os.path.join(root, "profiles", f"{tag}_sq_by_stage.json")) as f:
     want = json.load(f)
+  want.pop("_stamp", None)
   assert got.keys() == want.keys() and len(got) == 8
   for stage in want:
     for k, v in want[stage].items():
@@ -615,27 +618,36 @@ def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows():
   assert got["proc_edge"]["lds_bank_conflict"] == 0.0
 
 
-def test_committed_traffic_summary_is_reproducible_from_the_committed_counter_rows():
-  """profiles/r03_final2_pmc_by_stage.json (L2 <-> fabric bytes per stage; roofline.traffic reads its processor
-  edge entry through profiles/pmc_traffic.json) from the committed FETCH_SIZE / WRITE_SIZE rows."""
+@pytest.mark.parametrize("tag", ["r03_final2", "r04_final"])
+def test_committed_traffic_summary_is_reproducible_from_the_committed_counter_rows(tag):
+  """profiles/<tag>_pmc_by_stage.json (L2 <-> fabric bytes per stage) from the committed FETCH_SIZE / WRITE_SIZE rows;
+  r04_final is also profiles/current_pmc_by_stage.json, what bench.py attaches as roofline.traffic when the loaded
+  library was built from the sources the passes ran on."""
   import json
   import os
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  rows = [os.path.join(root, "profiles", f"r03_final2_pmc_{c}_rowmlp_launches.csv") for c in ("FETCH_SIZE", "WRITE_SIZE")]
+  rows = [os.path.join(root, "profiles", f"{tag}_pmc_{c}_rowmlp_launches.csv") for c in ("FETCH_SIZE", "WRITE_SIZE")]
   out = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_by_stage.py"), *rows], check=True,
                        capture_output=True, text=True).stdout
   got = json.loads(out)
-  with open(os.path.join(root, "profiles", "r03_final2_pmc_by_stage.json")) as f:
+  with open(os.path.join(root, "profiles", f"{tag}_pmc_by_stage.json")) as f:
     want = json.load(f)
   for stage in want:
+    if stage == "_stamp":
+      continue
     for k, v in want[stage].items():
       if isinstance(v, (int, float)):
         assert abs(got[stage][k] - v) <= 1e-9 * max(1.0, abs(v)), (stage, k)
-  with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
-    table = json.load(f)
-  assert table["f16x3h:proc_edge"]["bytes_per_launch"] == want["proc_edge"]["traffic_bytes_per_launch"]
+  if tag == "r03_final2":
+    with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
+      table = json.load(f)
+    assert table["f16x3h:proc_edge"]["bytes_per_launch"] == want["proc_edge"]["traffic_bytes_per_launch"]
+  else:
+    with open(os.path.join(root, "profiles", "current_pmc_by_stage.json")) as f:
+      cur = json.load(f)
+    assert cur["proc_edge"] == want["proc_edge"] and len(cur["_stamp"]["src"]) == 16
 
 
 def test_bench_attaches_counters_only_from_a_profile_of_the_loaded_build(tmp_path):

@@ -43,14 +43,13 @@ def test_forty_step_rollout_at_headline_size(golden_dir):
   roll = rollout_device.DeviceRollout(model, std, mean, dstd)
   traj = roll.run(inputs, template, forcings)                      # [40, N_grid, 1, C_out], de-normalised: 38 GB in HBM
   torch.cuda.synchronize()
-  loop_ms = roll.last_loop_ms()
   assert torch.isfinite(traj).all()
   got = traj[:, torch.as_tensor(rows, device=traj.device), 0].cpu().numpy().astype(np.float64)
   per_step = [float(np.linalg.norm(got[s] - want[s]) / np.linalg.norm(want[s])) for s in range(n_have)]
   report = {"config": "0.25deg_37L_M6, 16 processor steps, 40 autoregressive steps, 256 sampled grid rows x 227 channels",
             "oracle": f"tests/golden/{FIXTURE} (torch-CPU fp32 oracle through rollout.chunked_prediction + InputsAndResiduals)",
             "rel_rmse_step_1_10_20_30_40": [per_step[k] for k in (0, 9, 19, 29, 39)], "rel_rmse_max": max(per_step),
-            "rel_rmse_per_step": per_step, "device_loop_ms_per_step": loop_ms / n_have}
+            "rel_rmse_per_step": per_step}       # (timing of this loop: bench.py's `rollout` -- here the first step builds the engine)
   print("ROLLOUT40_FULLSIZE_PARITY " + json.dumps(report))
   out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
   os.makedirs(out_dir, exist_ok=True)
