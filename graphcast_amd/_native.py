@@ -122,6 +122,11 @@ VARIANTS = {"main": ("libgcast_hip.so", "-DGC_PIPE=2")}
 
 
 def library_path(variant=None):
+  """The library to load: the in-tree product build, or -- A/B sessions only -- GCAST_LIB_PATH=<file>, a build of the
+  same sources with other -D switches (e.g. ab_libs/libgcast_noweave.so = -DGC_H_WEAVE=0)."""
+  if variant is None and os.environ.get("GCAST_LIB_PATH"):
+    path = os.environ["GCAST_LIB_PATH"]
+    return path if os.path.isabs(path) else os.path.join(os.path.dirname(_HERE), path)
   variant = variant or os.environ.get("GCAST_LIB_VARIANT", "main")
   return os.path.join(_CSRC, VARIANTS[variant][0])
 
