@@ -1328,9 +1328,16 @@ __global__ void prep_grid_input_kernel(int n_rows, int batch, int b, int c_in, i
 // state and the prediction are formed in LDS (thread t owns channels t, t + 256, ...: its table entries
 // are read once per block; the picks are 4-byte LDS reads) and leave as 16-byte stores of a contiguous
 // range again.  Same arithmetic, element for element, as the one-wave-per-row kernel of rounds 2-3
-// (2.33-2.43 ms per 0.25 deg step = 2.4 TB/s of useful bytes; this one 1.79 ms = 3.3 TB/s; two
+// (2.33-2.43 ms per 0.25 deg step = 2.4 TB/s of useful bytes; this one 1.79 ms = 3.3 TB/s with 8 rows per block,
+// 1.29 ms = 4.5 TB/s with 4 (round 4); two
 // direct-to-global variants of this round were no faster than the old one, profiles/r03_s18_* .. r03_s21_*).
-constexpr int kAdvRows = 8;        // 37 KiB of LDS at 474 -> 227 channels: four blocks per CU in different phases
+// (round 4, same-session A/B at the 0.25 deg shape, all bit-identical, profiles/r04_s14_*: 2 rows per block 1.90 ms -- 227
+//  channels x 2 rows is no multiple of four floats: the y side falls back to 4-byte copies --, 4 rows 1.29 ms = 4.5 TB/s,
+//  8 rows (rounds 3) 1.87 ms = 3.1 TB/s, 16 rows 2.32 ms: 18.5 KiB of LDS per block, eight blocks per CU in different phases)
+#ifndef GC_ADV_ROWS
+#define GC_ADV_ROWS 4
+#endif
+constexpr int kAdvRows = GC_ADV_ROWS;
 __device__ __forceinline__ void adv_copy(float* dst, const float* src, int n, bool vec, int t) {
   if (vec) {
     const int n4 = n >> 2;
@@ -1469,7 +1476,14 @@ int half_helpers_default();
 
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
-  if ((d.flags & GC_WG_HELPERS) || (!(d.flags & GC_WG_NO_HELPERS) && half_helpers_default()))
+  // Which form.  Asked for per launch (GC_WG_HELPERS / GC_WG_NO_HELPERS), or per process (GCAST_HELPERS); otherwise:
+  // a launch of at most one tile per CU runs one four-wave workgroup per CU anyway -- for the node-side launches (no
+  // gather, no segment-sum) the eight-wave form with its staging waves is faster per lone tile (1 deg step: processor
+  // node updates 2.24 -> 2.11 ms, profiles/r04_s13_*; the edge updates are NOT: 5.23 -> 5.37), so small node-side
+  // launches (small grids, the 8-way partition's ranks) take it; GCAST_HELPERS_SMALL=0 switches the rule off (A/B).
+  static const bool small_rule = [] { const char* e = std::getenv("GCAST_HELPERS_SMALL"); return !e || std::atoi(e) != 0; }();
+  const bool small = small_rule && !d.g0 && !d.seg && (d.n_rows + kHRows - 1) / kHRows <= GC_SCRATCH_SLOTS / 2;
+  if ((d.flags & GC_WG_HELPERS) || (!(d.flags & GC_WG_NO_HELPERS) && (half_helpers_default() || small)))
     return launch_rowmlp_half_d<MODE, ONEPASS>(d, s);
   const size_t lds = kHLdsFloats * sizeof(float);
   if (!g_h_attr_set[MODE][ONEPASS]) {
