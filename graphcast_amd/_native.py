@@ -138,7 +138,9 @@ def library_path(variant=None):
 # changing any result, so no test would notice).  Today: LINEAR 0, MLP_OUT 0, one-pass 0, the two-pass
 # MLP_LN 116 bytes (56 spilled VGPRs + 60 SGPRs parked in VGPR lanes, all outside the MFMA streams:
 # address and descriptor values around the prologue / epilogue), the bf16 tier 260.
-RESOURCE_LIMITS = {"rowmlp16h_kernel": dict(scratch=160, occupancy=2), "rowmlpbf_kernel": dict(scratch=320, occupancy=2)}
+RESOURCE_LIMITS = {"rowmlp16h_kernel": dict(scratch=160, occupancy=2), "rowmlpbf_kernel": dict(scratch=320, occupancy=2),
+                   # the eight-wave helper form (one 512-thread workgroup per CU = two waves per SIMD: the same 256-register budget)
+                   "rowmlp16d_kernel": dict(scratch=160, occupancy=2)}
 
 
 def check_resources(remarks, limits=None):
