@@ -740,3 +740,21 @@ def test_real_xarray_objects_are_adapted_at_the_predictor_boundary():
   data_vars, coords = xl.to_xarray(got)
   assert set(data_vars) == set(want.keys()) and data_vars["2m_temperature"][0] == want["2m_temperature"].dims
   assert "lat" in coords and coords["lat"][0] == ("lat",)
+
+
+def test_bench_weight_stream_bytes_of_a_launch():
+  """roofline.lds_fill (round 4): packed-weight bytes a half-N launch streams L2 -> LDS = tiles x 16 KiB quarters
+  (4 per layer-1 K chunk, 64 per 512-wide layer 2 / chained stage, 32 for the narrow output stage)."""
+  import bench
+  from graphcast_amd import _native as nat
+  op = nat.Op()
+  op.kind = nat.OP_ROWMLP
+  m = op.mlp
+  m.layout, m.prec, m.mode, m.n_rows, m.k0, m.k1 = nat.LAYOUT_HALF, nat.PREC_F16X3, nat.MODE_MLP_LN, 327680, 512, 0
+  assert bench.op_weight_stream_bytes(op) == 5120 * (64 + 64) * 16384          # the processor edge update: 10.7 GB
+  m.k1, m.n_chain = 512, 2
+  m.chain[0].kind, m.chain[1].kind = nat.CHAIN_SWISH, nat.CHAIN_NARROW
+  m.n_rows = 1038240
+  assert bench.op_weight_stream_bytes(op) == 16223 * (128 + 64 + 64 + 32) * 16384   # the decoder node update + output MLP
+  m.layout = nat.LAYOUT_CHUNKED
+  assert bench.op_weight_stream_bytes(op) == 0.0

@@ -152,3 +152,29 @@ def test_c_host_example_runs_and_agrees_with_the_python_hosts(tmp_path):
   print(f"C host (examples/plan_host.c) vs float64 oracle: rel-RMSE {err:.2e}; {run.stdout.strip().splitlines()[-1]}")
   assert err <= 2e-5
   nat_plan.close()
+
+
+def test_plan_range_check_raises_on_out_of_range_inputs(case):
+  """gc_plan_check_range (round 4): a GC_PREC_F16X3 plan fed a value beyond +-65504 reports GC_ERANGE at the host's next
+  synchronisation point (plan.NativePlan.check_range -> GcastRangeError); in range it stays silent, and the word is
+  cleared by the next gc_step_forward.  f32 plans never complain."""
+  from graphcast_amd import _native as nat
+  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"])
+  rng = np.random.default_rng(9)
+  x = rng.standard_normal((case["graphs"]["n_grid"], 1, case["c_in"])).astype(np.float32)
+  big = x.copy()
+  big[17, 0, 5] = 3.0e5
+  p = plan.NativePlan(case["graphs"], case["params"], precision="f16x3", half=True, **kw)
+  p(torch.from_numpy(x).to("cuda:0"))
+  p.check_range()
+  p(torch.from_numpy(big).to("cuda:0"))
+  with pytest.raises(nat.GcastRangeError, match="65504"):
+    p.check_range()
+  p(torch.from_numpy(x).to("cuda:0"))              # the next step clears the word
+  p.check_range()
+  p.close()
+  q = plan.NativePlan(case["graphs"], case["params"], precision="f32", half=False, **kw)
+  y = q(torch.from_numpy(big).to("cuda:0"))
+  q.check_range()
+  assert torch.isfinite(y).all()
+  q.close()
