@@ -90,7 +90,11 @@ __device__ __forceinline__ void g_quarter(f4 (&acc)[32], int nb0, const u4* wb, 
 // HELPERS = 1: waves 4-7 stage the ring (+ XV extra 16-byte global loads and XA VALU ops per quarter each);
 // HELPERS = 0: four waves, each multiplies AND stages its share of every quarter (the shipped structure, one
 // workgroup per CU).  RING = quarters in LDS (DMA runs RING - 1 quarters ahead).
-template <int HELPERS, int NG, int RING, int XV, int XA>
+// L2LIKE = 1: the multiplying wave's loop shaped like the real kernel's layer-2 pass -- 16 K steps unrolled, two quarters
+// each into accumulator sets 0-7 / 8-15, the B operand of K step cc taken from register arrays hh[cc], hl[cc] (128
+// VGPRs of packed hidden values) -- instead of four quarters with one B operand: does the unrolled 32-quarter body,
+// or the register pressure, cost the ~110 cycles per quarter the real kernel lies above this skeleton?
+template <int HELPERS, int NG, int RING, int XV, int XA, int L2LIKE = 0>
 __global__ __launch_bounds__(HELPERS ? 512 : 256, HELPERS ? 2 : 1) void gh(const float* __restrict__ w,
                                                                            const f4* __restrict__ extra, f4* out,
                                                                            long long* cyc, int n_quarters) {
@@ -161,6 +165,37 @@ __global__ __launch_bounds__(HELPERS ? 512 : 256, HELPERS ? 2 : 1) void gh(const
       fl[q] = wb[q * 128 + 64];
     }
   }
+  if constexpr (L2LIKE) {
+    u4 hh[16], hl[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      hh[c] = reinterpret_cast<const u4*>(w)[lane + 64 * ((wave + c) & 7) + 512];
+      hl[c] = reinterpret_cast<const u4*>(w)[lane + 64 * ((wave + c) & 7) + 1024];
+    }
+    const long long t0 = __builtin_readcyclecounter();
+    // (n_quarters = 32 k + 1)
+#pragma unroll 1
+    for (int q0 = 0; q0 + 32 < n_quarters; q0 += 32) {
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int q = q0 + 2 * cc + j;
+          const u4* wb = reinterpret_cast<const u4*>(smem + ((2 * cc + j) % RING) * kQFloats) + lane;
+          const u4* wn = reinterpret_cast<const u4*>(smem + ((2 * cc + j + 1) % RING) * kQFloats) + lane;
+          (void)q;
+          g_quarter<NG>(acc, 8 * j, wb, wn, fh, fl, hh[cc], hl[cc]);
+        }
+      }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    f4 s2 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s2 += acc[i];
+    out[(size_t)blockIdx.x * 512 + tid] = s2;
+    if (tid == 0) cyc[2 * blockIdx.x] = t1 - t0;
+    return;
+  }
   const long long t0 = __builtin_readcyclecounter();
   // (n_quarters = 4 k + 1: k rounds over the four accumulator groups, the accumulator index a compile-time constant)
 #pragma unroll 1
@@ -190,11 +225,11 @@ __global__ __launch_bounds__(HELPERS ? 512 : 256, HELPERS ? 2 : 1) void gh(const
   if (tid == 0) cyc[2 * blockIdx.x] = t1 - t0;
 }
 
-template <int HELPERS, int NG, int RING, int XV, int XA>
+template <int HELPERS, int NG, int RING, int XV, int XA, int L2LIKE = 0>
 void run(const char* name, int blocks, const float* w, const f4* extra, f4* out, long long* cyc) {
-  const int nq = 4097;
+  const int nq = 4097;                     // (= 32 * 128 + 1 = 4 * 1024 + 1: fits both loop shapes)
   const size_t lds = RING * kQFloats * sizeof(float);
-  auto fn = gh<HELPERS, NG, RING, XV, XA>;
+  auto fn = gh<HELPERS, NG, RING, XV, XA, L2LIKE>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int threads = HELPERS ? 512 : 256;
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), lds, 0, w, extra, out, cyc, 65);
@@ -257,7 +292,9 @@ int main(int argc, char** argv) {
     case 11: run<1, 4, 4, 2, 32>("helpers + 2 loads + 32 x 4 VALU / quarter", blocks, w, extra, out, cyc); break;
     case 12: run<1, 2, 4, 2, 16>("helpers + 2 loads + 16 x 4 VALU / quarter; g2", blocks, w, extra, out, cyc); break;
     case 13: run<1, 4, 6, 0, 0>("helpers; groups of 4, ring 6 (LDS offsets beyond 64 KiB)", blocks, w, extra, out, cyc); break;
-    default: printf("usage: gh_skeleton <variant 0..13>\n");
+    case 14: run<1, 2, 4, 0, 0, 1>("helpers; layer-2-like loop (32 quarters unrolled, B from 128 VGPRs); g2, ring 4", blocks, w, extra, out, cyc); break;
+    case 15: run<0, 2, 4, 0, 0, 1>("own DMA; layer-2-like loop; g2, ring 4", blocks, w, extra, out, cyc); break;
+    default: printf("usage: gh_skeleton <variant 0..15>\n");
   }
   return 0;
 }
