@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""What the Dataset boundary costs when the caller hands over HOST buffers: GraphCast.__call__
+(reference graphcast.py:298-329) on numpy-backed Datasets at 0.25 deg / 37 levels -- stacking to [N_grid, B, C_in] on
+the host, one H2D copy (1.96 GB), the step on the MI355X, one D2H copy (0.94 GB), un-stacking into a Dataset --
+against the same call on device-resident (torch-backed) Datasets.  bench.py's `value` never includes any of this.
+
+    python scripts/host_boundary_bench.py [--iters 3] [--out gpurun_out/host_boundary.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as B                                   # noqa: E402
+from graphcast_amd import graphcast as gc           # noqa: E402
+from graphcast_amd import synthetic                 # noqa: E402
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--iters", type=int, default=3)
+  ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "host_boundary.json"))
+  args = ap.parse_args()
+  res, mesh_size, levels, gnn_steps = B.CONFIGS["0.25deg_37L_M6"]
+  task = gc.TASK
+  lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
+  c_out = gc.num_output_channels(task)
+  c_in = 2 * (5 + 6 * levels) + 2 * 5 + 2 + 5
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=gnn_steps, hidden_layers=1,
+                       radius_query_fraction_edge_length=0.6)
+  model = gc.GraphCast(cfg, task, params=B.fast_params(c_in, c_out, gnn_steps)).init_from_coordinates(lat, lon)
+  inputs, template, forcings = synthetic.make_example(task, lat, lon, num_target_steps=1)
+  dev_inputs, dev_forcings = synthetic.to_device(inputs, "cuda:0"), synthetic.to_device(forcings, "cuda:0")
+
+  def timed(fn):
+    fn()                                            # warm-up (builds the engine the first time)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(args.iters):
+      t0 = time.perf_counter()
+      out = fn()
+      torch.cuda.synchronize()
+      ts.append(time.perf_counter() - t0)
+      del out
+    return float(np.median(ts))
+
+  t_host = timed(lambda: model(inputs, template, forcings))
+  t_dev = timed(lambda: model(dev_inputs, template, dev_forcings))
+  x = torch.randn((len(lat) * len(lon), 1, c_in), device="cuda:0")
+  y = torch.empty((len(lat) * len(lon), 1, c_out), device="cuda:0")
+  t_step = timed(lambda: model.forward_grid_node_features(x, y))
+  res_ = {"config": "GraphCast 0.25deg_37L_M6, batch 1, one 6-h step per call",
+          "seconds_per_call": {"host_datasets_in_and_out (stack + H2D + step + D2H + unstack)": t_host,
+                               "device_resident_datasets (stack + step + unstack on the device)": t_dev,
+                               "tensor_boundary (forward_grid_node_features: what bench.py times)": t_step},
+          "bytes": {"h2d": 4 * x.numel(), "d2h": 4 * y.numel()},
+          "steps_per_second": {"host_boundary": 1.0 / t_host, "device_datasets": 1.0 / t_dev, "tensor_boundary": 1.0 / t_step}}
+  print(json.dumps(res_))
+  os.makedirs(os.path.dirname(args.out), exist_ok=True)
+  with open(args.out, "w") as f:
+    json.dump(res_, f, indent=1)
+
+
+if __name__ == "__main__":
+  main()
