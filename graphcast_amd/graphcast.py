@@ -281,14 +281,20 @@ class GraphCast(predictor_base.Predictor):
   # ---------------------------------------------------------------- Dataset boundary
   def __call__(self, inputs, targets_template, forcings, is_training: bool = False):
     """Reference :298-329.  ``inputs`` / ``forcings`` may hold numpy arrays (host datasets:
-    one H2D of the stacked features, one D2H of the outputs) or torch tensors already on the
-    device (rollouts that keep the state in HBM: nothing crosses PCIe)."""
+    one H2D per variable, one D2H per predicted variable; host Datasets come back) or torch
+    tensors already on the device (rollouts that keep the state in HBM: nothing crosses PCIe)."""
     del is_training
     import torch
     from graphcast_amd import xarray_lite as xl
     # (real xarray Datasets of a host that has xarray are adapted here; xarray_lite objects pass through)
     inputs, targets_template, forcings = xl.from_xarray(inputs), xl.from_xarray(targets_template), xl.from_xarray(forcings)
     self._maybe_init(np.asarray(inputs.coords["lat"].values), np.asarray(inputs.coords["lon"].values))
+    # Host (numpy-backed) Datasets: every variable is uploaded as it is and the stacking to [N_grid, B, C_in] -- and
+    # the un-stacking of the outputs -- runs ON THE DEVICE; only the variables cross PCIe.  (Stacking 1.96 GB on the
+    # host and copying the stacked array cost 0.82 s per 0.25 deg call, profiles/r04_s18_*.)
+    host_in = not any(xl._is_torch(v.data) for v in inputs.variables.values())
+    if host_in and str(self._device).startswith("cuda"):
+      inputs, forcings = self._upload(inputs), self._upload(forcings)
     features = self._inputs_to_grid_node_features(inputs, forcings)
     on_device = torch.is_tensor(features)
     if on_device:
@@ -301,8 +307,25 @@ class GraphCast(predictor_base.Predictor):
     # synchronisation point: the host path copies y back right below; device-resident Dataset rollouts pay one
     # stream wait per step -- rollout_device.DeviceRollout checks once per run instead.)
     self._engine.check_range()
-    return self._grid_node_outputs_to_prediction(y if on_device else y.cpu().numpy(),
-                                                 targets_template)
+    if host_in and on_device:
+      # host Datasets in -> host Datasets out: ONE D2H copy of the contiguous [N_grid, B, C_out] block into pinned
+      # memory (torch's caching host allocator hands the same pages back on the next call); the Dataset's variables
+      # are numpy views of it, as the host un-stacking makes them
+      y_host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
+      y_host.copy_(y)
+      return self._grid_node_outputs_to_prediction(y_host.numpy(), targets_template)
+    return self._grid_node_outputs_to_prediction(y if on_device else y.cpu().numpy(), targets_template)
+
+  def _upload(self, dataset):
+    """Host Dataset -> device Dataset, one H2D copy per variable straight from the caller's arrays: the HIP runtime
+    moves pageable memory at the link's rate on the MI355X host (50-56 GB/s measured, scripts/probes/pcie_probe.py;
+    staging through pinned pages first was SLOWER, the host-side copy being the slow leg)."""
+    import torch
+    from graphcast_amd import xarray_lite as xl
+    def put(v):
+      data = v.data if xl._is_torch(v.data) else torch.from_numpy(np.ascontiguousarray(v.data))
+      return xl.Variable(v.dims, data.to(self._device, non_blocking=True))
+    return xl.Dataset._construct({k: put(v) for k, v in dataset._vars.items()}, dict(dataset._coords))
 
   def _inputs_to_grid_node_features(self, inputs, forcings):
     """Datasets -> [num_grid_nodes, batch, num_channels] (reference :680-699)."""

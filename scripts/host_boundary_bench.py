@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """What the Dataset boundary costs when the caller hands over HOST buffers: GraphCast.__call__
-(reference graphcast.py:298-329) on numpy-backed Datasets at 0.25 deg / 37 levels -- stacking to [N_grid, B, C_in] on
-the host, one H2D copy (1.96 GB), the step on the MI355X, one D2H copy (0.94 GB), un-stacking into a Dataset --
-against the same call on device-resident (torch-backed) Datasets.  bench.py's `value` never includes any of this.
+(reference graphcast.py:298-329) on numpy-backed Datasets at 0.25 deg / 37 levels -- one H2D copy per variable
+(1.96 GB in all), stacking to [N_grid, B, C_in] on the device, the step, un-stacking on the device, one D2H copy per
+predicted variable (0.94 GB) -- against the same call on device-resident (torch-backed) Datasets.  bench.py's `value` never includes any of this.
 
     python scripts/host_boundary_bench.py [--iters 3] [--out gpurun_out/host_boundary.json]
 """
@@ -55,10 +55,18 @@ def main():
   x = torch.randn((len(lat) * len(lon), 1, c_in), device="cuda:0")
   y = torch.empty((len(lat) * len(lon), 1, c_out), device="cuda:0")
   t_step = timed(lambda: model.forward_grid_node_features(x, y))
+  # the host call's pieces, timed one by one
+  t_upload = timed(lambda: (model._upload(inputs), model._upload(forcings)))
+  y_host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
+  t_d2h = timed(lambda: y_host.copy_(y))
+  t_unstack = timed(lambda: model._grid_node_outputs_to_prediction(y_host.numpy(), template))
+  t_stack = timed(lambda: model._inputs_to_grid_node_features(dev_inputs, dev_forcings))
   res_ = {"config": "GraphCast 0.25deg_37L_M6, batch 1, one 6-h step per call",
-          "seconds_per_call": {"host_datasets_in_and_out (stack + H2D + step + D2H + unstack)": t_host,
+          "seconds_per_call": {"host_datasets_in_and_out (H2D per variable + device stack + step + device unstack + D2H per variable)": t_host,
                                "device_resident_datasets (stack + step + unstack on the device)": t_dev,
                                "tensor_boundary (forward_grid_node_features: what bench.py times)": t_step},
+          "host_call_pieces_seconds": {"upload_variables": t_upload, "stack_on_device": t_stack, "d2h_into_pinned": t_d2h,
+                                       "unstack_on_host": t_unstack},
           "bytes": {"h2d": 4 * x.numel(), "d2h": 4 * y.numel()},
           "steps_per_second": {"host_boundary": 1.0 / t_host, "device_datasets": 1.0 / t_dev, "tensor_boundary": 1.0 / t_step}}
   print(json.dumps(res_))
