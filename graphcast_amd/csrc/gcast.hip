@@ -1474,6 +1474,14 @@ template <int MODE, int ONEPASS>
 int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s);
 int half_helpers_default();
 
+// gc_rowmlp_desc.tile_queue: from GC_TILE_QUEUE_MIN_ROUNDS tiles per workgroup on (GC_TILE_QUEUE_ANY: whenever there is
+// a second round at all).  With fewer the static walk is the better schedule: its few second-round tiles land on
+// DISTINCT CUs (workgroups b and b + 256 share one), where a lone workgroup runs at 0.6 of the pair's tile time; the
+// queue hands them to whoever finishes first -- often both workgroups of one CU.
+inline bool tile_queue_pays(const gc_rowmlp_desc& d, int tiles, int grid) {
+  return d.tile_queue && (tiles >= GC_TILE_QUEUE_MIN_ROUNDS * grid || ((d.flags & GC_TILE_QUEUE_ANY) && tiles > grid));
+}
+
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   // Which form.  Asked for per launch (GC_WG_HELPERS / GC_WG_NO_HELPERS), or per process (GCAST_HELPERS); otherwise:
@@ -1501,6 +1509,7 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   const int grid = tiles < cap ? tiles : cap;
   gc_rowmlp_desc dd = d;
   if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
+  if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
   hipLaunchKernelGGL((rowmlp16h_kernel<MODE, ONEPASS>), dim3(grid), dim3(256), lds, s, dd);
   return check_launch("rowmlp16h_kernel");
 }
@@ -1534,6 +1543,7 @@ int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
   const int grid = tiles < cap ? tiles : cap;
   gc_rowmlp_desc dd = d;
   if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
+  if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
   hipLaunchKernelGGL((rowmlp16d_kernel<MODE, ONEPASS>), dim3(grid), dim3(512), lds, s, dd);
   return check_launch("rowmlp16d_kernel");
 }
@@ -1569,7 +1579,9 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   }
   const int tiles = (d.n_rows + 16 * NW - 1) / (16 * NW);
   const int slots = GC_SCRATCH_SLOTS * 4 / NW;        // persistent: 8 / NW workgroups per CU
-  hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, d);
+  gc_rowmlp_desc dd = d;
+  if (!tile_queue_pays(dd, tiles, tiles < slots ? tiles : slots)) dd.tile_queue = nullptr;
+  hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, dd);
   return check_launch("rowmlpbf_kernel");
 }
 
@@ -1644,6 +1656,14 @@ static bool pow2_or_unset(float s) {
 int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (!dp) return fail(GC_EINVAL, "gc_rowmlp: null descriptor");
   gc_rowmlp_desc d = *dp;
+  // gc_rowmlp_desc.tile_queue: the persistent kernels' dynamic tile queue (GC_LAYOUT_HALF launches and the
+  // GC_PREC_BF16 tier); GCAST_TILE_QUEUE=0 (read once) walks the tiles statically whatever the descriptor says (A/B).
+  static const bool queue_off = [] { const char* e = std::getenv("GCAST_TILE_QUEUE"); return e && std::atoi(e) == 0; }();
+  if (d.tile_queue && (reinterpret_cast<size_t>(d.tile_queue) & 7))
+    return fail(GC_EINVAL, "gc_rowmlp: tile_queue must be an 8-byte aligned pair of device words");
+  if (d.tile_queue && d.prec != GC_PREC_BF16 && d.layout != GC_LAYOUT_HALF)
+    return fail(GC_EINVAL, "gc_rowmlp: tile_queue is a feature of the persistent kernels (GC_LAYOUT_HALF, GC_PREC_BF16)");
+  if (queue_off) d.tile_queue = nullptr;
   if (d.prec == GC_PREC_BF16) return rowmlp_bf16(d, static_cast<hipStream_t>(stream));
   if (!pow2_or_unset(d.w1_scale) || !pow2_or_unset(d.w2_scale))
     return fail(GC_EINVAL, "gc_rowmlp: w1_scale / w2_scale must be powers of two");

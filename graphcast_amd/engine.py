@@ -164,6 +164,7 @@ class StepEngine:
   # (deep_gnn.DeepGNN, conditioned.ConditionedEncoderDecoder)
   helpers_min_rows = 0
   range_flag = None
+  tile_queue = None
   check_all_rows = False        # True: EVERY launch with layer-1 rows carries the range flag (their latents are external)
 
   def __init__(self, graphs: Mapping, params: Mapping, *, num_steps: int, c_in: int, c_out: int,
@@ -243,6 +244,8 @@ class StepEngine:
     ds.layout = nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED
     if self.half and mode == nat.MODE_MLP_LN and self.prec != nat.PREC_BF16:
       ds.scratch = self._scratch_slots().data_ptr()
+    if self.half:
+      ds.tile_queue = self._tile_queue().data_ptr()
     ds.n_chain = len(chain)
     for k, st in enumerate(chain):
       c = ds.chain[k]
@@ -288,6 +291,14 @@ class StepEngine:
       self.scratch = torch.empty((nat.SCRATCH_FLOATS,), dtype=torch.float32, device=self.dev)
       self._keep.append(self.scratch)
     return self.scratch
+
+  def _tile_queue(self):
+    """The persistent kernels' dynamic tile queue (include/gcast.h: gc_rowmlp_desc.tile_queue): two device words,
+    zero here and left zero by every launch; shared by all launches of the engine like the parking slots (they run
+    one after another on one stream)."""
+    if self.tile_queue is None:
+      self.tile_queue = torch.zeros((2,), dtype=torch.int32, device=self.dev)
+    return self.tile_queue
 
   def _op_mlp(self, tag, desc):
     op = nat.Op()

@@ -112,6 +112,12 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
                                   * waves, four waves that stage the weight ring for them (csrc/rowmlp_half.inc:
                                   * rowmlp16d_kernel) -- instead of two four-wave workgroups.  Bit-identical results. */
 #define GC_WG_NO_HELPERS 64      /* ... or pin the four-wave form (neither flag: the build's default, GC_HELPERS_DEFAULT) */
+#define GC_TILE_QUEUE_ANY 128    /* gc_rowmlp_desc.tile_queue: hand the tiles out dynamically whenever the launch has more
+                                  * tiles than workgroups (default: only from GC_TILE_QUEUE_MIN_ROUNDS tiles per
+                                  * workgroup on -- below that the static walk places the few second-round tiles on
+                                  * distinct CUs, which measured better: processor node updates, 641 tiles on 512
+                                  * workgroups, 5.5 -> 6.1 ms per step with the queue, profiles/r04_s22_*) */
+#define GC_TILE_QUEUE_MIN_ROUNDS 4
 #ifndef GC_HELPERS_DEFAULT
 #define GC_HELPERS_DEFAULT 0
 #endif
@@ -231,6 +237,15 @@ typedef struct gc_rowmlp_desc {
    * geopotential is ~5e5) pass it, the host reads it at its next synchronisation point and raises.  Never cleared
    * by a launch.  NULL: no check (rows a LayerNorm has produced). */
   int* range_flag;
+  /* Persistent kernels (GC_LAYOUT_HALF, GC_PREC_BF16), optional: TWO device words (8-byte aligned), both ZERO before
+   * the first launch that is given them.  A launch of at least GC_TILE_QUEUE_MIN_ROUNDS tiles per workgroup (any
+   * launch of more tiles than workgroups with GC_TILE_QUEUE_ANY) then hands its tiles out dynamically -- a workgroup takes its first tile by its index and every further one from word 0 -- instead of
+   * walking b, b + grid, ...: the launch ends when the work does, not when the slowest workgroup has done a fixed
+   * share (the workgroups of one launch differ by +-13 % in speed on the MI355X, csrc/rowmlp_half.inc).  Results do
+   * not depend on it.  Every launch leaves both words zero (word 1 counts the workgroups that have left; the last
+   * one clears the pair), so launches that run ONE AFTER ANOTHER on a stream may share them -- the contract of
+   * `scratch`; launches that may overlap need their own pair.  NULL: static walk. */
+  int* tile_queue;
 } gc_rowmlp_desc;
 
 int gc_rowmlp(const gc_rowmlp_desc* desc, void* stream);

@@ -104,11 +104,17 @@ def main():
   prec = nat.PRECISIONS["f16x3"]
   s1 = s2 = float(sc)
 
+  # the dynamic tile queue (gc_rowmlp_desc.tile_queue); PROBE_QUEUE=0: the static walk b, b + grid, ...
+  queue = torch.zeros((2,), dtype=torch.int32, device=dev)
+  use_queue = os.environ.get("PROBE_QUEUE", "1") != "0"
+
   def desc(mode, n_rows, layout):
     d = nat.RowMlpDesc()
     d.mode, d.n_rows, d.prec, d.layout = mode, n_rows, prec, layout
     d.w1_scale, d.w2_scale = s1, s2
     d.scratch = scratch.data_ptr()
+    if use_queue and layout == nat.LAYOUT_HALF:
+      d.tile_queue = queue.data_ptr()
     return d
 
   def proc_edge(layout):
@@ -190,6 +196,8 @@ def main():
     d.w2p, d.b2 = wb1.data_ptr(), vec.data_ptr()
     d.ln_scale, d.ln_offset, d.b1 = one.data_ptr(), vec.data_ptr(), vec.data_ptr()
     d.scratch = scratch.data_ptr()            # (only the trace build looks at it)
+    if use_queue:
+      d.tile_queue = queue.data_ptr()
     return d
 
   def proc_edge_bf16(layout):
@@ -244,6 +252,22 @@ def main():
       per_cu = np.unique(t[:, 13], return_counts=True)[1]
       row["workgroups_per_cu_min_max"] = [int(per_cu.min()), int(per_cu.max())]
       row["shader_ghz_implied"] = round(row["wave0_cycles_total_mean"] / (row["wg_wall_us_mean"] * 1e3), 3)
+      # how evenly the persistent workgroups finish (static schedule: workgroup b walks tiles b, b + grid, ...): the
+      # launch lasts until the LAST one is done; (max - mean) finish time is what a dynamic tile queue could recover
+      wg = t[:, 15].astype(np.int64)                   # which workgroup ran the tile (dynamic queue: not tile % grid)
+      grid = int(wg.max()) + 1
+      row["wg_schedule_queue"] = bool(use_queue)
+      t_first = float(t[:, 12].min())
+      row["tiles_per_workgroup_min_max"] = [int(np.bincount(wg, minlength=grid).min()), int(np.bincount(wg, minlength=grid).max())]
+      finish = np.array([t[wg == b, 14].max() for b in range(grid)], dtype=np.float64)
+      start = np.array([t[wg == b, 12].min() for b in range(grid)], dtype=np.float64)
+      busy = np.array([(t[wg == b, 14] - t[wg == b, 12]).sum() for b in range(grid)], dtype=np.float64)
+      us = lambda v: round(float(v) / 100.0, 2)
+      row["wg_schedule"] = {"grid": int(grid), "span_us": us(finish.max() - t_first),
+                            "first_start_us_max": us(start.max() - t_first),
+                            "finish_us_min_mean_max": [us(finish.min() - t_first), us(finish.mean() - t_first), us(finish.max() - t_first)],
+                            "busy_us_min_mean_max": [us(busy.min()), us(busy.mean()), us(busy.max())],
+                            "tail_frac_of_span": round(float((finish.max() - finish.mean()) / (finish.max() - t_first)), 4)}
       out[name] = row
       print("htrace", name, json.dumps(row), flush=True)
     with open(args.out, "w") as f:

@@ -319,6 +319,14 @@ def test_edge_block_with_segment_sum(dev, case):
   pipeline()
   assert torch.equal(first, agg) and torch.equal(first_out, out)
   d.flags = 0
+  # round 4: with the dynamic tile queue (more tiles than workgroups in "many_tiles"; a no-op otherwise) the
+  # segment-sum's partial rows are still addressed by the TILE: the same bits whichever workgroup ran it
+  queue = torch.zeros((2,), dtype=torch.int32, device=dev)
+  d.tile_queue, d.flags = queue.data_ptr(), nat.TILE_QUEUE_ANY
+  agg.fill_(float("nan")); out.zero_()
+  pipeline()
+  assert torch.equal(first, agg) and torch.equal(first_out, out) and queue.tolist() == [0, 0]
+  d.flags = 0
   # ---- the ONE-PASS formulation of the same launch (GC_W2_NATURAL: no layer-1 GEMM, so every K chunk's
   #      hidden columns are formed on the fly from the addend rows; W2 in the natural K order; no scratch),
   #      with three addend sources and with two (the encoder edge update has no receiver term)
@@ -330,11 +338,11 @@ def test_edge_block_with_segment_sum(dev, case):
     d.w2p, d.scratch = w2n.data_ptr(), None
     if not with_g1:
       d.g1, d.idx1 = None, None
-    d.flags = nat.W2_NATURAL | nat.WG_HELPERS               # (first in the helper-wave form: must give the same bits)
+    d.flags = nat.W2_NATURAL | nat.WG_HELPERS | nat.TILE_QUEUE_ANY      # (first in the helper-wave form: must give the same bits)
     agg.fill_(float("nan")); out.zero_()
     pipeline()
     helper_bits = (agg.clone(), out.clone())
-    d.flags = nat.W2_NATURAL
+    d.flags = nat.W2_NATURAL | nat.TILE_QUEUE_ANY
     agg.fill_(float("nan"))
     out.zero_()
     pipeline()
@@ -597,6 +605,18 @@ def test_half_persistent_loop_revisits_scratch_slots(dev):
     d.flags = flags
     run(d)
     assert torch.equal(first[0], out) and torch.equal(first[1], y), flags
+  # round 4: the dynamic tile queue (gc_rowmlp_desc.tile_queue: a workgroup takes its first tile by index, every
+  # further one from a device counter) -- which workgroup runs which tile changes nothing; every launch leaves the
+  # two words zero, so the next launch (and the next form) can reuse them
+  queue = torch.zeros((2,), dtype=torch.int32, device=dev)
+  d.tile_queue = queue.data_ptr()
+  for flags in (nat.WG_NO_HELPERS, nat.WG_HELPERS, nat.WG_NO_HELPERS):
+    out.zero_(); y.zero_()
+    d.flags = flags | nat.TILE_QUEUE_ANY      # (by default only launches of >= 4 tiles per workgroup use the queue)
+    run(d)
+    assert torch.equal(first[0], out) and torch.equal(first[1], y), ("tile queue", flags)
+    assert queue.tolist() == [0, 0], queue.tolist()
+  d.tile_queue = None
   d.flags = nat.WG_NO_HELPERS
   assert_close(out.cpu().numpy(), res.astype(np.float64) + _mlp_ln_want(p), "rows over many tiles per slot")
   h32 = out.cpu().numpy().astype(np.float64)
