@@ -120,3 +120,10 @@ esac
 #   s11  = s10 with scripts/probes/f16x3_weave_valu_bursts.patch's one-pass weave built in
 #   s14  ADV_LIBS="rows2:@...;rows4:@...;rows16:@..." python scripts/advance_probe.py     (-DGC_ADV_ROWS=<n> builds)
 #   final / final2   bash scripts/final_session.sh r04_final
+#   s18 / s19  python scripts/host_boundary_bench.py   (host-stacked Datasets; then per-variable upload + device stacking)
+#              python scripts/probes/pcie_probe.py      (pageable / pinned H2D, D2H rates of the box)
+#   s20  python scripts/probes/hipgraph_step_probe.py   (the step replayed as one hipGraph vs eager enqueue)
+#   s21  HALF_TRACE=1 PROBE_QUEUE=0 PROBE_SHAPES=proc_edge,node_grid,dec_edge python -u scripts/half_probe.py   (static walk: per-workgroup finish times)
+#   s22  = s21 with PROBE_QUEUE=1 + scripts/session.sh bench-ab r04_s22 "GCAST_TILE_QUEUE=0" "GCAST_TILE_QUEUE=1" ... (queue on every launch with a second round)
+#   s23  scripts/session.sh bench-ab r04_s23 "GCAST_TILE_QUEUE=0" "GCAST_TILE_QUEUE=1" ...   (queue from 4 tiles per workgroup on: shipped)
+#   final3   bash scripts/final_session.sh r04_final3   (-> profiles/r04_final_*, current_*; the static-walk build's kept as r04_final2_static_walk_*)
