@@ -258,6 +258,14 @@ def main():
       grid = int(wg.max()) + 1
       row["wg_schedule_queue"] = bool(use_queue)
       t_first = float(t[:, 12].min())
+      # where the speed differences sit: per XCD (smid = xcc << 6 | se << 4 | cu on gfx94x / gfx950) and per CU
+      smid = t[:, 13].astype(np.int64)
+      wall = (t[:, 14] - t[:, 12]).astype(np.float64) / 100.0
+      row["by_xcd"] = {int(x): {"tiles": int((smid >> 6 == x).sum()), "tile_us_mean": round(float(wall[smid >> 6 == x].mean()), 2)}
+                       for x in np.unique(smid >> 6)}
+      row["by_shader_engine_tile_us_mean"] = {int(x): round(float(wall[((smid >> 4) & 3) == x].mean()), 2) for x in np.unique((smid >> 4) & 3)}
+      cu_mean = np.array([wall[smid == c].mean() for c in np.unique(smid)])
+      row["per_cu_tile_us_mean_p5_p50_p95"] = [round(float(np.percentile(cu_mean, q)), 2) for q in (5, 50, 95)]
       row["tiles_per_workgroup_min_max"] = [int(np.bincount(wg, minlength=grid).min()), int(np.bincount(wg, minlength=grid).max())]
       finish = np.array([t[wg == b, 14].max() for b in range(grid)], dtype=np.float64)
       start = np.array([t[wg == b, 12].min() for b in range(grid)], dtype=np.float64)
