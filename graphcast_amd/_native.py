@@ -22,7 +22,7 @@ WG_ROWS_64, WG_ROWS_128 = 4, 8                    # GC_WG_ROWS_64 / GC_WG_ROWS_1
 LAYOUT_CHUNKED, LAYOUT_HALF = 0, 2
 LATENT = 512
 TILE_MAP_XCD = 16                                 # GC_TILE_XCD
-TILE_QUEUE_ANY = 128                              # GC_TILE_QUEUE_ANY: the dynamic tile queue from two tiles per workgroup on
+TILE_QUEUE_ANY = 128                              # GC_TILE_QUEUE_ANY: the dynamic tile queue whenever a launch has a second round
 WG_HELPERS, WG_NO_HELPERS = 32, 64                # GC_WG_HELPERS / GC_WG_NO_HELPERS (eight-wave form of a GC_LAYOUT_HALF launch)
 TILE_ROWS = 64
 K_CHUNK = 32

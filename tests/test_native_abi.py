@@ -58,6 +58,35 @@ def test_argument_validation_needs_no_gpu(built):
   assert lib.gc_prep_grid_input(10, 1, 0, 471, None, 3, None, 474, None, None) == -1
 
 
+def test_python_constants_mirror_the_header():
+  """The ctypes side repeats the header's #defines by hand: every one of them is compared here."""
+  text = open(os.path.join(ROOT, "include", "gcast.h")).read()
+  defines = {m.group(1): m.group(2) for m in re.finditer(r"^#define (GC_[A-Z0-9_]+) \(?(-?[0-9.]+)f?\)?\s", text, flags=re.M)}
+  mirror = dict(GC_LATENT=nat.LATENT, GC_TILE_ROWS=nat.TILE_ROWS, GC_K_CHUNK=nat.K_CHUNK, GC_SCRATCH_SLOTS=nat.SCRATCH_SLOTS,
+                GC_EINVAL=nat.EINVAL, GC_ELAUNCH=nat.ELAUNCH, GC_ERANGE=nat.ERANGE, GC_F16X3_MAX=nat.F16X3_MAX,
+                GC_ROWS_F32=nat.ROWS_F32, GC_W2_NATURAL=nat.W2_NATURAL, GC_WG_ROWS_64=nat.WG_ROWS_64,
+                GC_WG_ROWS_128=nat.WG_ROWS_128, GC_TILE_XCD=nat.TILE_MAP_XCD, GC_WG_HELPERS=nat.WG_HELPERS,
+                GC_WG_NO_HELPERS=nat.WG_NO_HELPERS, GC_TILE_QUEUE_ANY=nat.TILE_QUEUE_ANY, GC_MAX_CHAIN=nat.MAX_CHAIN)
+  for name, value in mirror.items():
+    assert name in defines, f"{name} not found in include/gcast.h"
+    assert float(defines[name]) == float(value), (name, defines[name], value)
+  flags = [mirror[k] for k in ("GC_ROWS_F32", "GC_W2_NATURAL", "GC_WG_ROWS_64", "GC_WG_ROWS_128", "GC_TILE_XCD",
+                               "GC_WG_HELPERS", "GC_WG_NO_HELPERS", "GC_TILE_QUEUE_ANY")]
+  assert sorted(flags) == [1 << i for i in range(len(flags))], "gc_rowmlp_desc.flags bits must be distinct"
+
+
+def test_tile_queue_arguments_are_validated(built):
+  lib = built.lib()
+  d = nat.RowMlpDesc()
+  d.mode, d.n_rows, d.prec, d.layout = nat.MODE_MLP_LN, 64, nat.PREC_F16X3, nat.LAYOUT_HALF
+  d.tile_queue = 0x1004                                  # (never dereferenced: validation comes first)
+  assert lib.gc_rowmlp(ctypes.byref(d), None) == nat.EINVAL
+  assert b"tile_queue must be an 8-byte aligned pair" in lib.gc_last_error()
+  d.tile_queue, d.layout, d.prec = 0x1008, nat.LAYOUT_CHUNKED, nat.PREC_F32
+  assert lib.gc_rowmlp(ctypes.byref(d), None) == nat.EINVAL
+  assert b"tile_queue is a feature of the persistent kernels" in lib.gc_last_error()
+
+
 def test_header_is_plain_c_and_the_c_host_example_links():
   """include/gcast.h must be consumable from C (the drop-in boundary is a C-ABI): the example host
   compiles as strict C99 and links against the built library (it needs a GPU to RUN; on the MI355X
