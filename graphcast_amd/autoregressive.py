@@ -59,6 +59,7 @@ class Predictor(predictor_base.Predictor):
             .tail(time=num_inputs)
             .assign_coords(time=inputs.coords["time"].variable))
 
+  @predictor_base.host_datasets_on_device
   def __call__(self, inputs, targets_template, forcings, **kwargs):
     constant_inputs = self._get_and_validate_constant_inputs(inputs, targets_template, forcings)
     self._validate_targets_and_forcings(targets_template, forcings)

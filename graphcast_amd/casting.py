@@ -77,6 +77,7 @@ class _Bf16Wrapper(predictor_base.Predictor):
     self._enabled = enabled
     self._predictor = predictor
 
+  @predictor_base.host_datasets_on_device
   def __call__(self, inputs, targets_template, forcings, **kwargs):
     if not self._enabled:
       return self._predictor(inputs, targets_template, forcings, **kwargs)

@@ -317,15 +317,9 @@ class GraphCast(predictor_base.Predictor):
     return self._grid_node_outputs_to_prediction(y if on_device else y.cpu().numpy(), targets_template)
 
   def _upload(self, dataset):
-    """Host Dataset -> device Dataset, one H2D copy per variable straight from the caller's arrays: the HIP runtime
-    moves pageable memory at the link's rate on the MI355X host (50-56 GB/s measured, scripts/probes/pcie_probe.py;
-    staging through pinned pages first was SLOWER, the host-side copy being the slow leg)."""
-    import torch
+    """Host Dataset -> device Dataset (xarray_lite.to_device: one pageable H2D copy per variable)."""
     from graphcast_amd import xarray_lite as xl
-    def put(v):
-      data = v.data if xl._is_torch(v.data) else torch.from_numpy(np.ascontiguousarray(v.data))
-      return xl.Variable(v.dims, data.to(self._device, non_blocking=True))
-    return xl.Dataset._construct({k: put(v) for k, v in dataset._vars.items()}, dict(dataset._coords))
+    return xl.to_device(dataset, self._device)
 
   def _inputs_to_grid_node_features(self, inputs, forcings):
     """Datasets -> [num_grid_nodes, batch, num_channels] (reference :680-699)."""

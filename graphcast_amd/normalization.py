@@ -103,6 +103,7 @@ class InputsAndResiduals(predictor_base.Predictor):
   def _normalised_io(self, inputs, forcings):
     return normalize(inputs, *self._state_stats), normalize(forcings, *self._state_stats)
 
+  @predictor_base.host_datasets_on_device
   def __call__(self, inputs, targets_template, forcings, **kwargs):
     inputs, targets_template, forcings = (xarray.from_xarray(inputs), xarray.from_xarray(targets_template),
                                           xarray.from_xarray(forcings))

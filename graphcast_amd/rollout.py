@@ -190,13 +190,7 @@ def chunked_prediction_generator(
 
 def _to_host(ds: xarray.Dataset) -> xarray.Dataset:
   """``jax.device_get`` of the reference (:362): torch-backed variables -> numpy."""
-  def get(v):
-    data = v.data
-    if xarray._is_torch(data):
-      data = data.detach().cpu().numpy()
-    return xarray.Variable(v.dims, data)
-  return xarray.Dataset._construct({k: get(v) for k, v in ds._vars.items()},
-                                   {k: get(v) for k, v in ds._coords.items()})
+  return xarray.to_host(ds)
 
 
 def chunked_prediction(

@@ -94,11 +94,4 @@ def make_stats(task_config, seed=100, dtype=np.float32):
 def to_device(dataset, device):
   """Dataset with every data variable moved to ``device`` as a torch tensor
   (coordinates stay numpy) -- the ``device_put_fn`` for HBM-resident rollouts."""
-  import torch
-  def put(v):
-    data = v.data
-    if not xarray._is_torch(data):
-      data = torch.from_numpy(np.ascontiguousarray(data))
-    return xarray.Variable(v.dims, data.to(device))
-  return xarray.Dataset._construct({k: put(v) for k, v in dataset._vars.items()},
-                                   dict(dataset._coords))
+  return xarray.to_device(dataset, device)

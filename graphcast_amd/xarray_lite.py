@@ -785,6 +785,31 @@ def zeros_like(obj, dtype=None):
 
 
 # ----------------------------------------------------------------------------- real-xarray boundary
+def is_host(dataset) -> bool:
+  """True for a Dataset none of whose data variables is a torch tensor (numpy-backed: host memory)."""
+  return isinstance(dataset, Dataset) and not any(_is_torch(v.data) for v in dataset._vars.values())
+
+
+def to_device(dataset, device):
+  """Dataset with every data variable on ``device`` as a torch tensor (coordinates stay numpy): one H2D copy per
+  variable straight from the caller's arrays -- the HIP runtime moves pageable memory at the link's rate on the
+  MI355X host (50-56 GB/s, scripts/probes/pcie_probe.py; staging through pinned pages first measured slower)."""
+  import torch
+  def put(v):
+    data = v.data if _is_torch(v.data) else torch.from_numpy(np.ascontiguousarray(v.data))
+    return Variable(v.dims, data.to(device, non_blocking=True))
+  return Dataset._construct({k: put(v) for k, v in dataset._vars.items()}, dict(dataset._coords))
+
+
+def to_host(dataset):
+  """``jax.device_get`` of the reference (rollout.py:362): torch-backed variables and coordinates -> numpy."""
+  def get(v):
+    data = v.data
+    return Variable(v.dims, data.detach().cpu().numpy() if _is_torch(data) else data)
+  return Dataset._construct({k: get(v) for k, v in dataset._vars.items()},
+                            {k: get(v) for k, v in dataset._coords.items()})
+
+
 def is_lite(obj) -> bool:
   return isinstance(obj, (Dataset, DataArray, Variable))
 

@@ -55,6 +55,16 @@ def main():
   x = torch.randn((len(lat) * len(lon), 1, c_in), device="cuda:0")
   y = torch.empty((len(lat) * len(lon), 1, c_out), device="cuda:0")
   t_step = timed(lambda: model.forward_grid_node_features(x, y))
+  # reference-style use: the normalisation wrapper around the predictor, called on host Datasets -- with the
+  # wrapper's Dataset arithmetic on the device (predictor_base.host_datasets_on_device: the outermost wrapper
+  # uploads) and, for comparison, in numpy on the host (GCAST_WRAPPERS_ON_HOST=1)
+  from graphcast_amd import normalization
+  mean, std, dstd = synthetic.make_stats(task)
+  wrapped = normalization.InputsAndResiduals(model, std, mean, dstd)
+  t_wrapped = timed(lambda: wrapped(inputs, template, forcings))
+  os.environ["GCAST_WRAPPERS_ON_HOST"] = "1"
+  t_wrapped_host = timed(lambda: wrapped(inputs, template, forcings))
+  del os.environ["GCAST_WRAPPERS_ON_HOST"]
   # the host call's pieces, timed one by one
   t_upload = timed(lambda: (model._upload(inputs), model._upload(forcings)))
   y_host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
@@ -64,7 +74,9 @@ def main():
   res_ = {"config": "GraphCast 0.25deg_37L_M6, batch 1, one 6-h step per call",
           "seconds_per_call": {"host_datasets_in_and_out (H2D per variable + device stack + step + device unstack + D2H per variable)": t_host,
                                "device_resident_datasets (stack + step + unstack on the device)": t_dev,
-                               "tensor_boundary (forward_grid_node_features: what bench.py times)": t_step},
+                               "tensor_boundary (forward_grid_node_features: what bench.py times)": t_step,
+                               "InputsAndResiduals(GraphCast) on host datasets, wrapper arithmetic on the device": t_wrapped,
+                               "InputsAndResiduals(GraphCast) on host datasets, wrapper arithmetic in numpy on the host": t_wrapped_host},
           "host_call_pieces_seconds": {"upload_variables": t_upload, "stack_on_device": t_stack, "d2h_into_pinned": t_d2h,
                                        "unstack_on_host": t_unstack},
           "bytes": {"h2d": 4 * x.numel(), "d2h": 4 * y.numel()},

@@ -758,3 +758,33 @@ def test_bench_weight_stream_bytes_of_a_launch():
   assert bench.op_weight_stream_bytes(op) == 16223 * (128 + 64 + 64 + 32) * 16384   # the decoder node update + output MLP
   m.layout = nat.LAYOUT_CHUNKED
   assert bench.op_weight_stream_bytes(op) == 0.0
+
+
+def test_wrappers_pass_host_datasets_through_when_there_is_no_gpu_predictor():
+  """predictor_base.host_datasets_on_device uploads only around a predictor that lives on a GPU: a chain without a
+  device (or on the CPU) gets the caller's numpy-backed Datasets unchanged, and device_of finds the innermost
+  predictor's device through any number of wrappers."""
+  from graphcast_amd import casting, normalization, predictor_base, synthetic
+  from graphcast_amd import graphcast as gc
+  lat, lon = np.arange(-90, 91, 30.0), np.arange(0, 360, 30.0)
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, lat, lon)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  seen = []
+
+  class Inner(predictor_base.Predictor):
+    _device = None
+    def __call__(self, inputs, targets_template, forcings, **kw):
+      seen.append(all(isinstance(v.data, np.ndarray) for v in inputs._vars.values()))
+      return xarray.Dataset({k: (v.dims, np.zeros(v.shape, np.float32)) for k, v in targets_template._vars.items()},
+                            coords=dict(targets_template._coords))
+
+  chain = normalization.InputsAndResiduals(casting.Bfloat16Cast(Inner(), enabled=False), std, mean, dstd)
+  assert predictor_base.device_of(chain) is None
+  out = chain(inputs, template, forcings)
+  assert seen == [True] and all(isinstance(v.data, np.ndarray) for v in out._vars.values())
+  Inner._device = "cpu"
+  assert predictor_base.device_of(chain) == "cpu"
+  chain(inputs, template, forcings)
+  assert seen == [True, True]
+  Inner._device = "cuda:0"
+  assert predictor_base.device_of(chain) == "cuda:0"

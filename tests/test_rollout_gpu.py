@@ -113,6 +113,36 @@ def test_normalised_rollout_resident_in_hbm(setup):
   np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)
 
 
+def test_wrapper_chain_on_host_datasets_runs_on_the_device(setup):
+  """Reference-style use -- host (numpy) Datasets into InputsAndResiduals(Bfloat16Cast-less GraphCast) through the
+  autoregressive Predictor: the OUTERMOST wrapper uploads once, every wrapper's Dataset arithmetic and the feedback
+  run on device tensors (the GraphCast call sees torch-backed inputs), and host Datasets come back with the same
+  values as the device-resident path (predictor_base.host_datasets_on_device)."""
+  from graphcast_amd import autoregressive
+  model, _ = setup
+  n_steps = 2
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, num_target_steps=n_steps, seed=11)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  seen = []
+
+  class Spy(predictor_base.Predictor):
+    _device = model._device
+    def __call__(self, inputs, targets_template, forcings, **kw):
+      seen.append(all(torch.is_tensor(v.data) and v.data.is_cuda for v in inputs._vars.values()))
+      return model(inputs, targets_template, forcings, **kw)
+
+  assert predictor_base.device_of(autoregressive.Predictor(normalization.InputsAndResiduals(Spy(), std, mean, dstd))) == model._device
+  dut = autoregressive.Predictor(normalization.InputsAndResiduals(Spy(), std, mean, dstd))
+  got_host = dut(inputs, template, forcings)
+  assert seen == [True] * n_steps
+  put = lambda ds: synthetic.to_device(ds, "cuda:0")
+  got_dev = dut(put(inputs), template, put(forcings))
+  for k in template.keys():
+    assert isinstance(got_host[k].data, np.ndarray) and got_host[k].dims == got_dev[k].dims
+    assert torch.is_tensor(got_dev[k].data) and got_dev[k].data.is_cuda
+    np.testing.assert_array_equal(got_host[k].values, got_dev[k].values)
+
+
 def test_device_rollout_matches_dataset_rollout(setup):
   """rollout_device.DeviceRollout (gc_advance_state fusing normalisation + residual + window
   roll) against rollout.chunked_prediction(InputsAndResiduals(GraphCast)) on the same device
