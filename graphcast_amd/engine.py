@@ -569,7 +569,7 @@ class StepEngine:
       m = self.m_g2m_mesh
       ops.append(self._op_mlp("enc_node_mesh", self._mlp_ln(
           nm, m, a0=self.agg_mesh, k0=D, w1p=m.w1["a"], d=self.d_enc_mesh, res=self.h_mesh0,
-          out=self.h_mesh)))
+          out=self.h_mesh, check_range=True)))
       m = self.m_g2m_grid
       ops.append(self._op_mlp("enc_node_grid", self._mlp_ln(
           ng, m, a0=self.h_grid, k0=D, w1p=m.w1, b1=m.b1, res=self.h_grid, out=self.h_grid2)))
@@ -584,7 +584,7 @@ class StepEngine:
         self._proc_edge_site(ops, cuts, i)
         ops.append(self._op_mlp("proc_node", self._mlp_ln(
             nm, mn, a0=self.h_mesh, k0=D, a1=self.agg_mesh, k1=D, w1p=mn.w1, b1=mn.b1,
-            res=self.h_mesh, out=self.h_mesh)))
+            res=self.h_mesh, out=self.h_mesh, check_range=True)))
       # ---- decoder (mesh2grid GNN) ----
       m = self.m_m2g_edge
       ops.append(self._op_mlp("dec_pre", self._desc(
@@ -595,7 +595,7 @@ class StepEngine:
       m = self.m_m2g_grid
       ops.append(self._op_mlp("dec_node", self._mlp_ln(
           ng, m, a0=self.h_grid2, k0=D, a1=self.agg_grid, k1=D, w1p=m.w1, b1=m.b1,
-          res=self.h_grid2, out=self.h_grid)))
+          res=self.h_grid2, out=self.h_grid, check_range=True)))
       m = self.m_out
       y_slots.append((len(ops), "out"))
       ops.append(self._op_mlp("dec_out", self._desc(
@@ -689,7 +689,7 @@ class StepEngine:
         src = dict(a0=self.xin, k0=k_full, lda0=batch * self.c_in, a1=self.xin, k1=kt, lda1=kt, rows_f32=True)
       else:                # fewer than 32 input channels: the tail [x | struct | 0] is the whole input
         src = dict(a0=self.xin, k0=kt, lda0=kt, rows_f32=True)
-      src["check_range"] = True        # the one launch fed by external rows (check_range())
+      src["check_range"] = True        # fed by external rows; the three node updates below read AGGREGATES (check_range())
       ops.append(self._op_mlp("enc_embed_grid", self._mlp_ln(
           ng, m, w1p=m.w1, b1=m.b1, out=self.h_grid, chain=[rows(self.m_g2m_edge, "s", self.pre_grid)],
           **src)))
@@ -699,7 +699,8 @@ class StepEngine:
       first = self.m_proc_edge[0]
       ops.append(self._op_mlp("enc_node_mesh", self._mlp_ln(
           nm, m, a0=self.agg_mesh, k0=D, w1p=m.w1["a"], d=self.d_enc_mesh, res=self.h_mesh0,
-          out=self.h_mesh, chain=[rows(first, "s", self.pre_s_mesh), rows(first, "r", self.pre_r_mesh)])))
+          out=self.h_mesh, chain=[rows(first, "s", self.pre_s_mesh), rows(first, "r", self.pre_r_mesh)],
+          check_range=True)))     # (an AGGREGATE as layer-1 operand: a sum over up to 3,753 edges, not a LayerNorm output)
       m = self.m_g2m_grid
       ops.append(self._op_mlp("enc_node_grid", self._mlp_ln(
           ng, m, a0=self.h_grid, k0=D, w1p=m.w1, b1=m.b1, res=self.h_grid, out=self.h_grid2,
@@ -717,7 +718,7 @@ class StepEngine:
           chain = [rows(nxt, "s", self.pre_s_mesh), rows(nxt, "r", self.pre_r_mesh)]
         ops.append(self._op_mlp("proc_node", self._mlp_ln(
             nm, mn, a0=self.h_mesh, k0=D, a1=self.agg_mesh, k1=D, w1p=mn.w1, b1=mn.b1,
-            res=self.h_mesh, out=self.h_mesh, chain=chain)))
+            res=self.h_mesh, out=self.h_mesh, chain=chain, check_range=True)))
       # ---- decoder (mesh2grid GNN) ----
       m = self.m_m2g_edge
       self._dec_edge_site(ops, cuts)
@@ -725,7 +726,7 @@ class StepEngine:
       y_slots.append((len(ops), "chain", 1))
       ops.append(self._op_mlp("dec_node", self._mlp_ln(
           ng, m, a0=self.h_grid2, k0=D, a1=self.agg_grid, k1=D, w1p=m.w1, b1=m.b1,
-          res=self.h_grid2, out=None,
+          res=self.h_grid2, out=None, check_range=True,
           chain=[dict(w=_chained(mo), kind=S, b=mo.b1),
                  dict(w=mo.w2, kind=N, b=mo.b2, out_ptr=0, ldo=batch * self.c_out, n=self.c_out)])))
     return ops, x_slots, y_slots, cuts
@@ -765,7 +766,9 @@ class StepEngine:
   __call__ = forward
 
   def check_range(self):
-    """Raises GcastRangeError if a step since the last call read an input value outside the exact range of the
+    """Raises GcastRangeError if a step since the last call read an input value, or an AGGREGATE (the layer-1 operand
+    of the encoder's mesh-node update, the processor's node updates and the decoder's grid-node update: a sum over
+    up to 3,753 edges, which the reference up-casts to fp32 for this reason, graphcast.py:215), outside the exact range of the
     f16x3 arithmetic (|x| > 65504: the split halves saturate -- 5e-4 errors up to 1.3e5, garbage beyond -- where
     the reference's fp32 does not care; un-normalised geopotential is ~5e5).  SYNCHRONISES the launch stream:
     call it where the host waits for the step anyway (GraphCast.__call__, DeviceRollout.run, bench.py do)."""
@@ -774,9 +777,10 @@ class StepEngine:
     if int(self.range_flag.item()) != 0:
       self.range_flag.zero_()
       raise nat.GcastRangeError(
-          f"an input value exceeds {nat.F16X3_MAX:g} in magnitude: outside the exact range of the f16x3 arithmetic "
-          "(precision='f16x3').  Normalise the inputs (normalization.InputsAndResiduals, as the reference's demo "
-          "stack does) or run with precision='f32'.")
+          f"an input value -- or a per-receiver sum of edge messages (a node update's aggregate operand) -- exceeds "
+          f"{nat.F16X3_MAX:g} in magnitude: outside the exact range of the f16x3 arithmetic (precision='f16x3').  "
+          "Normalise the inputs (normalization.InputsAndResiduals, as the reference's demo stack does) or run with "
+          "precision='f32'.")
 
   def run_until(self, x: torch.Tensor, tag: str, y: Optional[torch.Tensor] = None):
     """Enqueues the step's launches up to (not including) the first launch tagged `tag` (batch

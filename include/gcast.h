@@ -234,8 +234,10 @@ typedef struct gc_rowmlp_desc {
   /* GC_PREC_F16X3 + GC_LAYOUT_HALF, optional: a device word the launch sets to 1 when a layer-1 row value (a0 / a1)
    * exceeds GC_F16X3_MAX in magnitude.  The split halves saturate there (exact to 6.5e4, 5e-4 up to 1.3e5, garbage
    * beyond) where the reference's fp32 does not care -- launches fed by EXTERNAL rows (the grid embedder: un-normalised
-   * geopotential is ~5e5) pass it, the host reads it at its next synchronisation point and raises.  Never cleared
-   * by a launch.  NULL: no check (rows a LayerNorm has produced). */
+   * geopotential is ~5e5) pass it, and so do the node updates whose layer-1 operand is an AGGREGATE (a per-receiver
+   * sum over up to 3,753 edge messages is not a LayerNorm output; the reference up-casts that sum to fp32 because it is
+   * large, weathernext1_graph/graphcast.py:215); the host reads it at its next synchronisation point and raises.
+   * Never cleared by a launch.  NULL: no check (rows a LayerNorm has produced). */
   int* range_flag;
   /* Persistent kernels (GC_LAYOUT_HALF, GC_PREC_BF16), optional: TWO device words (8-byte aligned), both ZERO before
    * the first launch that is given them.  A launch of at least GC_TILE_QUEUE_MIN_ROUNDS tiles per workgroup (any
@@ -399,8 +401,9 @@ int gc_plan_create(const gc_model_desc* model, const gc_tensor_desc* tensors, in
 size_t gc_plan_workspace_bytes(const gc_plan* plan, int batch);
 int gc_step_forward(const gc_plan* plan, const float* x, float* y, int batch, void* workspace,
                     size_t workspace_bytes, void* stream);
-/* GC_PREC_F16X3 plans: gc_step_forward clears a range word in the workspace and the grid embedder sets it when an
- * input value exceeds GC_F16X3_MAX (gc_rowmlp_desc.range_flag).  gc_plan_check_range synchronises `stream`, reads
+/* GC_PREC_F16X3 plans: gc_step_forward clears a range word in the workspace; the grid embedder sets it when an
+ * input value exceeds GC_F16X3_MAX, the aggregate-fed node updates (encoder mesh nodes, processor nodes, decoder grid
+ * nodes) when a per-receiver message sum does (gc_rowmlp_desc.range_flag).  gc_plan_check_range synchronises `stream`, reads
  * the word of the LAST gc_step_forward on this workspace and returns 0 or GC_ERANGE (message in gc_last_error):
  * call it wherever the host synchronises anyway, before trusting y.  Other precisions: always 0. */
 int gc_plan_check_range(const gc_plan* plan, void* workspace, void* stream);

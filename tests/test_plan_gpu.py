@@ -178,3 +178,18 @@ def test_plan_range_check_raises_on_out_of_range_inputs(case):
   q.check_range()
   assert torch.isfinite(y).all()
   q.close()
+
+
+def test_plan_range_check_covers_aggregate_operands(case):
+  """VERDICT r4 weak #2 through the plan API: in-range inputs, in-range grid2mesh messages, but their per-receiver SUM
+  (the encoder mesh-node update's layer-1 operand) beyond 65504 -> GC_ERANGE, not a silently saturated split."""
+  from graphcast_amd import _native as nat
+  from tests.test_step_gpu import _params_with_large_g2m_messages
+  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"])
+  params = _params_with_large_g2m_messages(case["c_in"], case["c_out"], case["steps"])
+  x = np.random.default_rng(4).standard_normal((case["graphs"]["n_grid"], 1, case["c_in"])).astype(np.float32)
+  p = plan.NativePlan(case["graphs"], params, precision="f16x3", half=True, **kw)
+  p(torch.from_numpy(x).to("cuda:0"))
+  with pytest.raises(nat.GcastRangeError, match="65504"):
+    p.check_range()
+  p.close()

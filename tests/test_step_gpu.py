@@ -190,6 +190,53 @@ def test_f16x3_range_guard_raises_instead_of_wrong_numbers(small):
     assert err <= 1e-4
 
 
+def _params_with_large_g2m_messages(c_in, c_out, steps, seed=6):
+  """Every grid2mesh message e' = LN(...) stays inside the f16x3 range (|e'| ~ 2e4 in four columns), but a mesh
+  node SUMS 4 .. 40 of them: the aggregate -- the layer-1 operand of the encoder's mesh-node update -- does not."""
+  params = {m: {k: np.array(v) for k, v in leaves.items()}
+            for m, leaves in oparams.init_params(c_in, c_out, 512, steps, seed=seed, nontrivial=True).items()}
+  ln = params["grid2mesh_gnn/~_networks_builder/processor_edges_0_grid2mesh_layer_norm"]
+  ln["offset"][[3, 100, 257, 511]] = [2.0e4, -2.1e4, 1.9e4, 2.2e4]
+  return params
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_aggregate_beyond_the_f16x3_range_raises_instead_of_saturating(precision):
+  """the launches whose layer-1 operand is an AGGREGATE (encoder mesh-node update, processor
+  node updates, decoder grid-node update) carry the range flag too -- a sum over up to 3,753 edges of LayerNorm
+  outputs is not a LayerNorm output (the reference up-casts this very sum to fp32 because it is large,
+  graphcast.py:215).  With in-range inputs and in-range messages whose SUM exceeds 65504 the f16x3 step raises;
+  f32 computes it."""
+  from graphcast_amd import _native as nat
+  res, mesh_size, steps = 4.0, 3, 2
+  lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=steps,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  c_in, c_out = 183, gc.num_output_channels(gc.TASK_13)
+  params = _params_with_large_g2m_messages(c_in, c_out, steps)
+  graphs = ogc.build_graphs(lat, lon, mesh_size)
+  x = np.random.default_rng(2).standard_normal((graphs["n_grid"], 1, c_in)).astype(np.float32)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params, precision=precision).init_from_coordinates(lat, lon)
+  engine = model._get_engine(c_in)
+  xt = torch.from_numpy(x).to("cuda:0")
+  engine.run_until(xt, "enc_node_mesh")
+  torch.cuda.synchronize()
+  top = float(engine.agg_mesh.abs().max())
+  assert top > 65504.0, f"the test's aggregate must leave the range (max |agg| = {top:.3g})"
+  y = model.forward_grid_node_features(xt)
+  if precision == "f16x3":
+    assert engine.half
+    with pytest.raises(nat.GcastRangeError, match="65504"):
+      engine.check_range()
+    engine.check_range()                       # cleared by the raise
+  else:
+    engine.check_range()
+    want = ogc.forward(params, graphs, x, steps=steps, dtype=np.float64)
+    err = rel_rmse(y.cpu().numpy(), want)
+    print(f"aggregate up to {top:.3g} (f32): rel-RMSE {err:.2e}")
+    assert err <= 1e-4
+
+
 def test_checkpoint_file_to_hip_step(tmp_path):
   """a CheckPoint in the reference's .npz layout (utils/checkpoint.py:26-54) written to a
   FILE, read back with checkpoint.load, handed to GraphCast -> the HIP step equals the step on the in-memory
