@@ -1489,7 +1489,13 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   // gather, no segment-sum) the eight-wave form with its staging waves is faster per lone tile (1 deg step: processor
   // node updates 2.24 -> 2.11 ms, profiles/r04_s13_*; the edge updates are NOT: 5.23 -> 5.37), so small node-side
   // launches (small grids, the 8-way partition's ranks) take it; GCAST_HELPERS_SMALL=0 switches the rule off (A/B).
-  static const bool small_rule = [] { const char* e = std::getenv("GCAST_HELPERS_SMALL"); return !e || std::atoi(e) != 0; }();
+  // GCAST_HELPERS=0 (the per-process "four-wave form everywhere" switch) turns it off as well; GC_WG_NO_HELPERS pins
+  // the four-wave form per launch.
+  static const bool small_rule = [] {
+    const char* e = std::getenv("GCAST_HELPERS_SMALL");
+    const char* h = std::getenv("GCAST_HELPERS");
+    return (!e || std::atoi(e) != 0) && !(h && std::atoi(h) == 0);
+  }();
   const bool small = small_rule && !d.g0 && !d.seg && (d.n_rows + kHRows - 1) / kHRows <= GC_SCRATCH_SLOTS / 2;
   if ((d.flags & GC_WG_HELPERS) || (!(d.flags & GC_WG_NO_HELPERS) && (half_helpers_default() || small)))
     return launch_rowmlp_half_d<MODE, ONEPASS>(d, s);

