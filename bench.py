@@ -337,17 +337,7 @@ def main():
     f_alg = flops_as_written(n_grid, g["n_mesh"], len(g["g2m"]["senders"]),
                              len(g["mesh"]["senders"]), len(g["m2g"]["senders"]),
                              c_in, c_out, gnn_steps)
-    # per-kernel durations, HIP events on the launch stream (gc_time_program)
-    arr, _ = engine.bind(x, y)
-    timed = engine.time_ops(x, iters=args.op_timing_iters)
-    tag_name = {v: k for k, v in eng.TAGS.items()}
-    per_stage = {}
-    for k, (tag, kind, ms) in enumerate(timed):
-      s = per_stage.setdefault(tag_name[tag], {"ms": 0.0, "launches": 0, "tflop": 0.0, "lds_fill_bytes": 0.0})
-      s["ms"] += ms
-      s["launches"] += 1
-      s["tflop"] += op_flops(arr[k]) / 1e12
-      s["lds_fill_bytes"] += op_weight_stream_bytes(arr[k])
+    per_stage = stage_table(engine, x, y, args.op_timing_iters)
     dominant = max(per_stage, key=lambda s: per_stage[s]["ms"])
     dom = per_stage[dominant]
     achieved = dom["tflop"] / (dom["ms"] / 1e3) if dom["ms"] > 0 else 0.0
@@ -406,11 +396,7 @@ def main():
             "step_frac_executed": executed_tflop / (ms_per_step / 1e3) / peak,
             "step_frac_as_written": f_alg / 1e12 / (ms_per_step / 1e3) / peak,
             # every stage against the same peak (executed FLOPs of its launches / its HIP-event time)
-            "stages": {k: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflop": round(v["tflop"], 4),
-                           "achieved": (v["tflop"] / (v["ms"] / 1e3) if v["ms"] > 0 else 0.0),
-                           "frac": (v["tflop"] / (v["ms"] / 1e3) / peak if v["ms"] > 0 else 0.0),
-                           "lds_fill_tb_per_s": round(v["lds_fill_bytes"] / (v["ms"] / 1e3) / 1e12, 2) if v["ms"] > 0 else 0.0}
-                       for k, v in sorted(per_stage.items()) if v["tflop"] > 0}},
+            "stages": stages_summary(per_stage, peak)},
         "precision": precision,
         "tier": (None if precision in ("f16x3", "f32") else
                  "reduced-precision TIER line: the headline is the default f16x3 run (fp32-grade results)"),
@@ -428,6 +414,7 @@ def main():
     }
     if args.gpus == 1 and args.rollout_steps > 0 and args.config == "0.25deg_37L_M6":
       line["rollout"] = rollout_extra(model, task, lat, lon, args.rollout_steps)
+      line["rollout_api"] = rollout_api_extra(model, task, lat, lon, args.rollout_steps)
     if args.gpus == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(c_in, c_out, gnn_steps, f_alg, full_graphs=g,
                                           full_x=x.cpu().numpy())
@@ -436,6 +423,74 @@ def main():
     print(json.dumps(line))
   if distributed:
     dist.destroy_process_group()
+
+
+def stage_table(engine, x, y, iters):
+  """Per-stage totals of one step of `engine`: per-launch durations by HIP events on the launch stream
+  (gc_time_program), executed FLOPs and weight-stream bytes of every launch, summed by stage tag."""
+  from graphcast_amd import engine as eng
+  arr, _ = engine.bind(x, y)
+  timed = engine.time_ops(x, iters=iters)
+  tag_name = {v: k for k, v in eng.TAGS.items()}
+  per_stage = {}
+  for k, (tag, kind, ms) in enumerate(timed):
+    s = per_stage.setdefault(tag_name[tag], {"ms": 0.0, "launches": 0, "tflop": 0.0, "lds_fill_bytes": 0.0})
+    s["ms"] += ms
+    s["launches"] += 1
+    s["tflop"] += op_flops(arr[k]) / 1e12
+    s["lds_fill_bytes"] += op_weight_stream_bytes(arr[k])
+  return per_stage
+
+
+def stages_summary(per_stage, peak):
+  """Every stage against the same peak (executed FLOPs of its launches / its HIP-event time)."""
+  return {k: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflop": round(v["tflop"], 4),
+              "achieved": (v["tflop"] / (v["ms"] / 1e3) if v["ms"] > 0 else 0.0),
+              "frac": (v["tflop"] / (v["ms"] / 1e3) / peak if v["ms"] > 0 else 0.0),
+              "lds_fill_tb_per_s": round(v["lds_fill_bytes"] / (v["ms"] / 1e3) / 1e12, 2) if v["ms"] > 0 else 0.0}
+          for k, v in sorted(per_stage.items()) if v["tflop"] > 0}
+
+
+def exchange_probe(step, world, device, iters=5):
+  """The cost of ONE step's 18 halo exchanges on this rank, in isolation (HIP events around index_select +
+  all_to_all_single, no compute in between): the rank's real exchangers when it has remote senders; at N = 1, where
+  the real splits are empty, a SELF-exchange of the row counts an 8-way rank has on the 0.25 deg graphs (encoder
+  3,000 grid rows, 419 mesh rows per processor step, 240 decoder rows: DESIGN.md section 7) through the same
+  DistExchanger, so that the collective's launch + copy cost is a number before an 8-GPU node exists."""
+  import torch
+  from graphcast_amd import partition
+  eng_ = step.engine
+  real = any(sum(ex.send_counts) + sum(ex.recv_counts) > 0 for ex in step.exchangers.values())
+  if real:
+    exs = {name: (step.exchangers[name], eng_.halo_table(name)) for name in ("g2m", "mesh", "m2g")}
+    rows = {name: int(sum(ex.recv_counts)) for name, (ex, _) in exs.items()}
+  else:
+    rows = {"g2m": 3000, "mesh": 419, "m2g": 240}
+    exs = {}
+    for name, n in rows.items():
+      owned = eng_.owned_rows(name)
+      n = min(n, owned)
+      table = torch.zeros((owned + n, 512), dtype=torch.float32, device=device)
+      idx = [np.arange(0, n, dtype=np.int64) * (owned // n)] + [np.zeros(0, np.int64)] * (world - 1)
+      plan_ = partition.HaloPlan(np.zeros(n, np.int64), [n] + [0] * (world - 1), idx)
+      exs[name] = (partition.DistExchanger(plan_, owned, device), table)
+  def once():
+    exs["g2m"][0].exchange(exs["g2m"][1])
+    for _ in range(eng_.num_steps):
+      exs["mesh"][0].exchange(exs["mesh"][1])
+    exs["m2g"][0].exchange(exs["m2g"][1])
+  once()
+  torch.cuda.synchronize()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  for _ in range(iters):
+    once()
+  ev1.record()
+  torch.cuda.synchronize()
+  wall = 1e3 * (time.perf_counter() - t0) / iters
+  return {"exchanges_per_step": eng_.num_steps + 2, "rows_received": rows, "synthetic_self_exchange": not real,
+          "device_ms_per_step": ev0.elapsed_time(ev1) / iters, "host_wall_ms_per_step": wall}
 
 
 def rollout_extra(model, task, lat, lon, n_steps):
@@ -457,6 +512,50 @@ def rollout_extra(model, task, lat, lon, n_steps):
           "advance_state_ms": roll.advance_ms(), "finite": bool(torch.isfinite(last).all().item()),
           "what": f"{n_steps} x 6 h autoregressive steps, state + forcings resident in HBM (DeviceRollout), device-loop "
                   "time by HIP events; parity of this loop: tests/test_rollout40_fullsize_gpu.py"}
+
+
+def rollout_api_extra(model, task, lat, lon, n_steps):
+  """The same rollout through the REFERENCE's entry point (utils/rollout.py:326-565): `rollout.chunked_prediction_generator`
+  on HOST Datasets around the demo stack normalization.InputsAndResiduals(GraphCast), given as a plain closure -- the
+  fused device loop runs underneath (graphcast_amd/rollout.py: _fused_stack; first chunk cross-checked against the
+  closure itself), every chunk's [N_grid, 1, C_out] block is copied to pinned host memory on a side stream under the
+  next step, host Datasets are yielded.  Chunks are dropped as they come (40 kept frames are 38 GB of host memory:
+  `chunked_prediction` = this generator + one host concatenation).  `ms_per_step` = host wall time of the whole
+  generator loop / steps (uploads, the cross-check call and the last chunk's copy included)."""
+  import torch
+  from graphcast_amd import normalization, rollout, synthetic
+  inputs, template, forcings = synthetic.make_example(task, lat, lon, num_target_steps=n_steps)
+  mean, std, dstd = synthetic.make_stats(task)
+  stack = normalization.InputsAndResiduals(model, std, mean, dstd)
+  fn = lambda rng, inputs, targets_template, forcings: stack(inputs, targets_template, forcings)
+
+  def consume(tmpl, forc):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n, host, finite = 0, True, True
+    for chunk in rollout.chunked_prediction_generator(fn, None, inputs, tmpl, 1, forc):
+      v = chunk["2m_temperature"].data
+      host = host and isinstance(v, np.ndarray)
+      finite = finite and bool(np.isfinite(np.asarray(v).reshape(-1)[::4097]).all())
+      n += 1
+      del chunk
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0), n, host, finite
+
+  consume(template.isel(time=slice(0, 2)), forcings.isel(time=slice(0, 2)))           # warm-up: tables, pinned pages
+  ms, n, host, finite = consume(template, forcings)
+  os.environ["GCAST_ROLLOUT_FUSED"] = "0"
+  try:
+    k = min(n_steps, 4)
+    ms_generic, _, _, _ = consume(template.isel(time=slice(0, k)), forcings.isel(time=slice(0, k)))
+  finally:
+    del os.environ["GCAST_ROLLOUT_FUSED"]
+  return {"steps": n, "ms_per_step": ms / max(n, 1), "steps_per_second": 1e3 * n / ms, "host_datasets_out": host,
+          "finite_sampled": finite, "generic_loop_ms_per_step": ms_generic / k,
+          "what": f"{n_steps} x 6 h steps through rollout.chunked_prediction_generator(lambda around InputsAndResiduals(GraphCast)) on "
+                  "HOST Datasets: host wall time incl. upload, first-chunk cross-check and the per-chunk D2H (0.94 GB, "
+                  "overlapped); generic_loop = the same call with GCAST_ROLLOUT_FUSED=0 (the predictor called chunk by "
+                  "chunk); parity: tests/test_rollout_gpu.py (bitwise = DeviceRollout)"}
 
 
 def partition_main(args, rank, world, device, distributed):
@@ -504,9 +603,41 @@ def partition_main(args, rank, world, device, distributed):
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   elapsed = float(t.item())
   step.engine.check_range()
+  # every rank's shard must be finite (rank 0's alone says nothing about the others)
+  fin = torch.tensor([1 if bool(torch.isfinite(y).all().item()) else 0], dtype=torch.int32, device=device)
+  dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+  finite = bool(fin.item())
+  # per-rank roofline: this rank's launches timed one by one (HIP events, no exchange in between), max over ranks per stage
+  precision = step.engine.precision
+  peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
+  per_stage = stage_table(step.engine, x, y, args.op_timing_iters)
+  names = sorted(per_stage)
+  ms = torch.tensor([per_stage[k]["ms"] for k in names], dtype=torch.float64, device=device)
+  dist.all_reduce(ms, op=dist.ReduceOp.MAX)          # (every rank has the same stage names: the same launch program)
+  exch = exchange_probe(step, world, device)
   if rank == 0:
     halo = {k: int(len(pl.halo_global)) for k, (pl, _) in partition.tables_of(mine).items()}
-    precision = step.engine.precision
+    stages = stages_summary(per_stage, peak)
+    for k, v in zip(names, ms.tolist()):
+      if k in stages:
+        stages[k]["ms_max_over_ranks"] = round(v, 3)
+    dominant = max(stages, key=lambda k: stages[k]["ms"])
+    dom = per_stage[dominant]
+    compute_ms = float(sum(ms.tolist()))
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:      # the same whole step on the host cores (rank 0, N = 1 only)
+      f_alg = flops_as_written(g["n_grid"], g["n_mesh"], len(g["g2m"]["senders"]), len(g["mesh"]["senders"]),
+                               len(g["m2g"]["senders"]), c_in, c_out, gnn_steps)
+      cpu = cpu_baseline(c_in, c_out, gnn_steps, f_alg, full_graphs=g,
+                         full_x=np.random.default_rng(0).standard_normal((g["n_grid"], 1, c_in), dtype=np.float32))
+    roofline = {"bound": "mfma", "kernel": f"rowmlp16h_kernel<MLP_LN> stage {dominant} (rank 0's share of the launch)",
+                "achieved": stages[dominant]["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": stages[dominant]["frac"],
+                "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"], "traffic": None,
+                "mfma_flops_per_algorithmic_flop": 3.0 if precision == "f16x3" else 1.0,
+                "stages": stages, "rank_compute_ms_per_step_max_over_ranks": compute_ms,
+                "exchange": exch,
+                "note": "per-rank launches timed one by one (gc_time_program); a rank's launches are 1/N of the step's "
+                        "rows -- few tiles per CU: see DESIGN.md section 7"}
     print(json.dumps({
         "metric": "6-h rollout steps/sec at 0.25deg/37-level",
         "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -518,8 +649,9 @@ def partition_main(args, rank, world, device, distributed):
                                   f"edges, 18 halo exchanges per step = one RCCL all_to_all_single each",
                    "rank0_rows": {"grid": mine.n_grid_owned, "mesh": mine.n_mesh_owned, "halo": halo},
                    "overlap": os.environ.get("GCAST_OVERLAP", "0") == "1"},
-        "roofline": None, "cpu_baseline": None,
-        "precision": precision, "output_finite": bool(torch.isfinite(y).all().item()),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "precision": precision, "output_finite": finite,
         "build": nat.lib().gc_build_info().decode()}))
   dist.destroy_process_group()
 

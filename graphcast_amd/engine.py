@@ -335,6 +335,8 @@ class StepEngine:
   def _run(self, ops):
     arr = (nat.Op * len(ops))(*ops)
     with torch.cuda.device(self.dev):
+      if self.tile_queue is not None:     # (see _clear_tile_queue; DeepGNN / ConditionedEncoderDecoder run through here)
+        self.tile_queue.zero_()
       nat.check(self.lib.gc_run_program(arr, len(ops), self._stream_ptr()), "gc_run_program")
 
   def _mlp_ln(self, n_rows, mlp: _Mlp, **kw):
@@ -757,30 +759,63 @@ class StepEngine:
         arr[slot[0]].mlp.chain[slot[2]].out = ptr
     return arr, y
 
+  def _clear_tile_queue(self):
+    """The two tile-queue words are left zero by every launch that COMPLETES; an aborted launch, or a caller who
+    overlapped two launches of one engine on different streams, would leave them non-zero and every later launch
+    would silently skip tiles.  One 8-byte memset at the head of each enqueued program (as gc_step_forward does)."""
+    if self.tile_queue is not None:
+      self.tile_queue.zero_()
+
   def forward(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
     arr, y = self.bind(x, y)
     with torch.cuda.device(self.dev):       # launches go to the engine's device whatever is current
+      self._clear_tile_queue()
       nat.check(self.lib.gc_run_program(arr, len(arr), self._stream_ptr()), "gc_run_program")
     return y
 
   __call__ = forward
 
-  def check_range(self):
+  _range_pending = None
+
+  def check_range(self, wait: bool = True):
     """Raises GcastRangeError if a step since the last call read an input value, or an AGGREGATE (the layer-1 operand
     of the encoder's mesh-node update, the processor's node updates and the decoder's grid-node update: a sum over
     up to 3,753 edges, which the reference up-casts to fp32 for this reason, graphcast.py:215), outside the exact range of the
     f16x3 arithmetic (|x| > 65504: the split halves saturate -- 5e-4 errors up to 1.3e5, garbage beyond -- where
     the reference's fp32 does not care; un-normalised geopotential is ~5e5).  SYNCHRONISES the launch stream:
-    call it where the host waits for the step anyway (GraphCast.__call__, DeviceRollout.run, bench.py do)."""
+    call it where the host waits for the step anyway (GraphCast.__call__ on host Datasets, DeviceRollout.run,
+    bench.py do); ``wait=False`` never blocks (a device-resident Dataset rollout must not wait on the host
+    once per step)."""
     if self.range_flag is None:
       return
-    if int(self.range_flag.item()) != 0:
-      self.range_flag.zero_()
-      raise nat.GcastRangeError(
-          f"an input value -- or a per-receiver sum of edge messages (a node update's aggregate operand) -- exceeds "
-          f"{nat.F16X3_MAX:g} in magnitude: outside the exact range of the f16x3 arithmetic (precision='f16x3').  "
-          "Normalise the inputs (normalization.InputsAndResiduals, as the reference's demo stack does) or run with "
-          "precision='f32'.")
+    if not wait:
+      # device-resident callers (torch-backed Datasets: nothing else makes the host wait): the word is copied to pinned
+      # memory behind the step and tested at the NEXT call -- the launches never clear it, so an out-of-range step is
+      # reported one call late at worst (and at the latest by the first blocking check: to_host, DeviceRollout.run)
+      if self._range_pending is not None:
+        host, done = self._range_pending
+        if not done.query():
+          return                         # (still in flight: test it next time)
+        self._range_pending = None
+        hit = int(host.item()) != 0
+      else:
+        hit = False
+      if not hit:
+        host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        host.copy_(self.range_flag, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.dev))
+        self._range_pending = (host, done)
+        return
+    elif int(self.range_flag.item()) == 0:
+      return
+    self._range_pending = None
+    self.range_flag.zero_()
+    raise nat.GcastRangeError(
+        f"an input value -- or a per-receiver sum of edge messages (a node update's aggregate operand) -- exceeds "
+        f"{nat.F16X3_MAX:g} in magnitude: outside the exact range of the f16x3 arithmetic (precision='f16x3').  "
+        "Normalise the inputs (normalization.InputsAndResiduals, as the reference's demo stack does) or run with "
+        "precision='f32'.")
 
   def run_until(self, x: torch.Tensor, tag: str, y: Optional[torch.Tensor] = None):
     """Enqueues the step's launches up to (not including) the first launch tagged `tag` (batch
@@ -789,6 +824,7 @@ class StepEngine:
     Verification hook (tests compare stage boundaries with the oracle); not on the product path."""
     arr, _ = self.bind(x, y)
     n = next(k for k in range(len(arr)) if arr[k].tag == TAGS[tag])
+    self._clear_tile_queue()
     nat.check(self.lib.gc_run_program(arr, n, self._stream_ptr()), "gc_run_program")
     return n
 
@@ -814,6 +850,7 @@ class StepEngine:
     # lists in lockstep.
     cuts = self._cuts[x.shape[1]]
     assert all(a[0] <= b[0] for a, b in zip(cuts[:-1], cuts[1:])), "cuts must be recorded in program order"
+    self._clear_tile_queue()
     segs = []
     lo = 0
     for hi, actions in [(c, [(kind, name)]) for c, name, kind in cuts] + [(len(arr), [])]:
@@ -837,6 +874,7 @@ class StepEngine:
   def time_ops(self, x, iters=3):
     """Per-op mean milliseconds measured with HIP events on the launch stream."""
     arr, _ = self.bind(x)
+    self._clear_tile_queue()
     ms = (ctypes.c_float * len(arr))()
     nat.check(self.lib.gc_time_program(arr, len(arr), iters, ms, self._stream_ptr()),
               "gc_time_program")

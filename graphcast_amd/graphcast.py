@@ -304,9 +304,10 @@ class GraphCast(predictor_base.Predictor):
     y = self.forward_grid_node_features(x)
     # the f16x3 arithmetic is exact only for |x| <= 65504 (normalised inputs are O(1)); the reference's fp32 takes
     # anything: a step fed e.g. un-normalised geopotential RAISES here instead of returning wrong numbers.  (A
-    # synchronisation point: the host path copies y back right below; device-resident Dataset rollouts pay one
-    # stream wait per step -- rollout_device.DeviceRollout checks once per run instead.)
-    self._engine.check_range()
+    # synchronisation point on the host path, which copies y back right below; device-resident Datasets are checked
+    # WITHOUT waiting: the flag is copied to pinned memory behind the step and tested at the next call -- the launches
+    # never clear it.)
+    self._engine.check_range(wait=host_in or not on_device)
     if host_in and on_device:
       # host Datasets in -> host Datasets out: ONE D2H copy of the contiguous [N_grid, B, C_out] block into pinned
       # memory (torch's caching host allocator hands the same pages back on the next call); the Dataset's variables

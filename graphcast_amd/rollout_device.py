@@ -168,11 +168,9 @@ class DeviceRollout:
     data = data if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data))
     return data.to(device=self._model._device, dtype=torch.float32).reshape(-1, data.shape[-1]).contiguous()
 
-  def run(self, inputs: xarray.Dataset, targets_template: xarray.Dataset,
-          forcings: xarray.Dataset, keep_trajectory: bool = True) -> torch.Tensor:
-    """Rolls out ``targets_template.sizes['time']`` steps.  Returns the trajectory
-    ``[T, N_grid, B, C_out]`` (de-normalised, device) -- or only the last step ``[1, ...]``
-    when ``keep_trajectory`` is False."""
+  def _prepare(self, inputs, targets_template, forcings):
+    """Everything before the first step: validation, the channel tables, the initial normalised state (through the
+    Dataset path once) and every target time's normalised forcing rows, uploaded once."""
     model = self._model
     dev = model._device
     inputs, targets_template, forcings = (xarray.from_xarray(inputs), xarray.from_xarray(targets_template),
@@ -186,7 +184,6 @@ class DeviceRollout:
     self._sizes = dict(inputs.sizes)
     self._build_tables(inputs, targets_template, forcings)
     tb = self._tables
-    # initial normalised state, through the Dataset path once
     norm_inputs = normalization.normalize(inputs, self._std, self._mean)
     norm_f0 = normalization.normalize(forcings.isel(time=slice(0, 1)), self._std, self._mean)
     feats = model._inputs_to_grid_node_features(norm_inputs, norm_f0)
@@ -195,32 +192,60 @@ class DeviceRollout:
     n_grid, batch, c_in = x.shape
     if c_in != tb["c_in"]:
       raise ValueError(f"state has {c_in} channels, tables describe {tb['c_in']}")
-    x_next = torch.empty_like(x)
-    y = torch.empty((n_grid, batch, tb["c_out"]), dtype=torch.float32, device=dev)
-    traj = torch.empty((n_steps if keep_trajectory else 1, n_grid, batch, tb["c_out"]),
-                       dtype=torch.float32, device=dev)
     # forcings of every target time, normalised, uploaded once (20 MB per 0.25 deg step)
     f_rows = [self._normalised_forcing_rows(forcings, t) for t in range(n_steps)]
+    return dict(x=x, x_next=torch.empty_like(x), n_steps=n_steps, f_rows=f_rows,
+                y=torch.empty((n_grid, batch, tb["c_out"]), dtype=torch.float32, device=dev),
+                out_shape=(n_grid, batch, tb["c_out"]))
+
+  def _loop(self, st, out=None):
+    """The step loop on a prepared state: yields ``(s, prediction)``; ``prediction`` = ``out[s]`` (``out[0]`` when the
+    buffer holds one slot) or a fresh ``[N_grid, B, C_out]`` tensor per step.  Enqueues only; never synchronises."""
+    model, tb = self._model, self._tables
+    dev = model._device
+    x, x_next, y, f_rows, n_steps = st["x"], st["x_next"], st["y"], st["f_rows"], st["n_steps"]
+    n_grid, batch, c_out = st["out_shape"]
     stream = lambda: ctypes.c_void_p(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
     for s in range(n_steps):
       model.forward_grid_node_features(x, y)
+      pred = (out[s if out.shape[0] > 1 else 0] if out is not None
+              else torch.empty(st["out_shape"], dtype=torch.float32, device=dev))
       d = nat.AdvanceDesc()
-      d.n_rows, d.c_in, d.c_out, d.n_forc = n_grid * batch, c_in, tb["c_out"], tb["n_forc"]
+      d.n_rows, d.c_in, d.c_out, d.n_forc = n_grid * batch, x.shape[-1], c_out, tb["n_forc"]
       d.x, d.y, d.x_next = x.data_ptr(), y.data_ptr(), x_next.data_ptr()
       d.f_cur = f_rows[s].data_ptr()
       d.f_next = f_rows[min(s + 1, n_steps - 1)].data_ptr()
       for k in ("src_x", "ax", "src_y", "ay", "src_f", "p_src_x", "p_ax", "p_ay", "p_b"):
         setattr(d, k, tb[k].data_ptr())
-      d.pred = traj[s if keep_trajectory else 0].data_ptr()
+      d.pred = pred.data_ptr()
       nat.check(self._lib.gc_advance_state(ctypes.byref(d), stream()), "gc_advance_state")
       x, x_next = x_next, x
-      self._last_advance = (d, x, x_next, y)          # (keeps the buffers of the descriptor alive)
+      self._last_advance = (d, x, x_next, y, pred)    # (keeps the buffers of the descriptor alive)
+      self.final_state = x
+      yield s, pred
+
+  def steps(self, inputs: xarray.Dataset, targets_template: xarray.Dataset, forcings: xarray.Dataset):
+    """The rollout as a generator: ``(s, prediction [N_grid, B, C_out])`` per lead time, a fresh de-normalised device
+    tensor each (the consumer may keep it or drop it -- nothing but the 2-frame state is retained here).  This is the
+    loop ``run`` executes -- the same kernels in the same order, bit for bit -- and what
+    ``rollout.chunked_prediction_generator`` runs underneath a recognised predictor stack."""
+    yield from self._loop(self._prepare(inputs, targets_template, forcings))
+
+  def run(self, inputs: xarray.Dataset, targets_template: xarray.Dataset,
+          forcings: xarray.Dataset, keep_trajectory: bool = True) -> torch.Tensor:
+    """Rolls out ``targets_template.sizes['time']`` steps.  Returns the trajectory
+    ``[T, N_grid, B, C_out]`` (de-normalised, device) -- or only the last step ``[1, ...]``
+    when ``keep_trajectory`` is False."""
+    st = self._prepare(inputs, targets_template, forcings)
+    traj = torch.empty((st["n_steps"] if keep_trajectory else 1,) + st["out_shape"], dtype=torch.float32,
+                       device=self._model._device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in self._loop(st, out=traj):
+      pass
     ev1.record()
-    self.final_state = x
     self._loop_events = (ev0, ev1)
-    model._engine.check_range()        # (once per run: an out-of-range input state raises instead of a wrong trajectory)
+    self._model._engine.check_range()        # (once per run: an out-of-range input state raises instead of a wrong trajectory)
     return traj
 
   def advance_ms(self, iters: int = 20) -> float:

@@ -1,0 +1,30 @@
+#!/bin/bash
+# The GPU-box sessions of round 5 in ONE file: `bash scripts/r05_sessions.sh <name>` runs one of them from the repository
+# root; results land under gpurun_out/r05_<name>/, what is kept is copied to profiles/r05_<name>_*.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+NAME=${1:?session name}
+OUT=gpurun_out/r05_$NAME; mkdir -p "$OUT"
+export TMPDIR=/tmp
+gate() { grep -q " passed" "$1" && ! grep -q "failed\|rror\|Timeout" "$1" || { echo "GATE: $2 failed"; tail -40 "$1"; exit 1; }; }
+show() { python - "$1" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(round(j["ms_per_step"], 3), {k: round(v["ms"], 3) for k, v in (j.get("roofline") or {}).get("stages", {}).items()})
+for k in ("rollout", "rollout_api"):
+  if j.get(k): print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in j[k].items() if a != "what"})
+if (j.get("roofline") or {}).get("exchange"): print("exchange", j["roofline"]["exchange"])
+PY
+}
+case "$NAME" in
+  s1)
+    # Round-5 session 1: the round's host-side changes on the GPU -- range flag on the aggregate-fed launches (engine +
+    # plan), the fused loop behind rollout.chunked_prediction, the bench line's rollout_api, --mode partition's per-rank
+    # roofline + exchange probe.
+    timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -5 "$OUT/pytest.log"
+    gate "$OUT/pytest.log" "host-side changes"
+    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
+    timeout 600 python bench.py --mode partition --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_partition_n1.json" 2> "$OUT/bench_partition.err"; echo "partition rc=$?"; show "$OUT/bench_partition_n1.json"
+    ;;
+  *) echo "unknown session $NAME"; exit 2;;
+esac

@@ -3,7 +3,9 @@ under normalization.InputsAndResiduals + rollout.chunked_prediction, with the st
 HBM between steps (torch-backed datasets), against the same wrappers around a Predictor whose
 step is the float64 CPU oracle.  Tolerance: rel-RMSE <= 1e-4 (BASELINE.json) after 3
 autoregressive steps; asserted 5e-5."""
+import contextlib
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -25,6 +27,21 @@ from oracle import params as oparams               # noqa: E402
 RES, MESH, STEPS = 6.0, 2, 2
 LAT = np.arange(-90, 90 + RES / 2, RES)
 LON = np.arange(0, 360, RES)
+
+
+@contextlib.contextmanager
+def generic_loop():
+  """rollout.chunked_prediction* with the predictor called chunk by chunk through its Dataset interface, as the
+  reference does -- not the fused device loop that round 5 runs underneath a recognised stack."""
+  old = os.environ.get("GCAST_ROLLOUT_FUSED")
+  os.environ["GCAST_ROLLOUT_FUSED"] = "0"
+  try:
+    yield
+  finally:
+    if old is None:
+      del os.environ["GCAST_ROLLOUT_FUSED"]
+    else:
+      os.environ["GCAST_ROLLOUT_FUSED"] = old
 
 
 class OraclePredictor(predictor_base.Predictor):
@@ -95,22 +112,24 @@ def test_normalised_rollout_resident_in_hbm(setup):
   want = rollout.chunked_prediction(lambda rng, **kw: ref(**kw), None, inputs, template, forcings)
   dut = wrap(model)
   put = lambda ds: synthetic.to_device(ds, "cuda:0")
-  chunks = list(rollout.chunked_prediction_generator(
-      lambda rng, **kw: dut(**kw), None, inputs, template, 1, forcings, device_put_fn=put))
-  assert len(chunks) == n_steps
-  assert all(c["temperature"].data.is_cuda for c in chunks)          # state never left the device
-  got = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
-                                   device_put_fn=put)
-  worst = 0.0
-  for k in template.keys():
-    assert got[k].shape == want[k].shape
-    for t in range(n_steps):
-      tax = got[k].dims.index("time")
-      e = _rel(np.take(got[k].values, t, axis=tax), np.take(want[k].values, t, axis=tax))
-      worst = max(worst, e)
-  print(f"3-step normalised rollout: worst per-variable per-step rel-RMSE {worst:.2e}")
-  assert worst < 5e-5
-  np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)
+  for name, ctx in (("generic loop", generic_loop()), ("fused loop", contextlib.nullcontext())):
+    with ctx:
+      chunks = list(rollout.chunked_prediction_generator(
+          lambda rng, **kw: dut(**kw), None, inputs, template, 1, forcings, device_put_fn=put))
+      assert len(chunks) == n_steps
+      assert all(c["temperature"].data.is_cuda for c in chunks)          # state never left the device
+      got = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
+                                       device_put_fn=put)
+    worst = 0.0
+    for k in template.keys():
+      assert got[k].shape == want[k].shape
+      for t in range(n_steps):
+        tax = got[k].dims.index("time")
+        e = _rel(np.take(got[k].values, t, axis=tax), np.take(want[k].values, t, axis=tax))
+        worst = max(worst, e)
+    print(f"3-step normalised rollout ({name}): worst per-variable per-step rel-RMSE {worst:.2e}")
+    assert worst < 5e-5
+    np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)
 
 
 def test_wrapper_chain_on_host_datasets_runs_on_the_device(setup):
@@ -155,8 +174,9 @@ def test_device_rollout_matches_dataset_rollout(setup):
   mean, std, dstd = synthetic.make_stats(gc.TASK_13)
   dut = normalization.InputsAndResiduals(model, std, mean, dstd)
   put = lambda ds: synthetic.to_device(ds, "cuda:0")
-  want = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
-                                    device_put_fn=put)
+  with generic_loop():
+    want = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
+                                      device_put_fn=put)
   roll = rollout_device.DeviceRollout(model, std, mean, dstd)
   traj = roll.run(inputs, template, forcings)
   assert traj.is_cuda and traj.shape[0] == n_steps
@@ -248,11 +268,12 @@ def test_device_rollout_in_the_bfloat16_tier(setup):
   mean, std, dstd = synthetic.make_stats(gc.TASK_13)
   dut = normalization.InputsAndResiduals(casting.Bfloat16Cast(model), std, mean, dstd)
   put = lambda ds: synthetic.to_device(ds, "cuda:0")
-  want = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
-                                    device_put_fn=put)
-  fp32 = rollout.chunked_prediction(
-      lambda rng, **kw: normalization.InputsAndResiduals(model, std, mean, dstd)(**kw), None, inputs, template,
-      forcings, device_put_fn=put)
+  with generic_loop():
+    want = rollout.chunked_prediction(lambda rng, **kw: dut(**kw), None, inputs, template, forcings,
+                                      device_put_fn=put)
+    fp32 = rollout.chunked_prediction(
+        lambda rng, **kw: normalization.InputsAndResiduals(model, std, mean, dstd)(**kw), None, inputs, template,
+        forcings, device_put_fn=put)
   with casting.precision_view(model, "bf16"):
     roll = rollout_device.DeviceRollout(model, std, mean, dstd)
     got = roll.to_dataset(roll.run(inputs, template, forcings), template)
@@ -265,3 +286,98 @@ def test_device_rollout_in_the_bfloat16_tier(setup):
         f"(the tier's own distance to the fp32-grade rollout: {tier:.2e})")
   assert worst <= tier              # closer to the wrapper chain than the tier is to fp32
   assert worst < 2e-2
+
+
+def _equal_datasets(a, b):
+  assert sorted(a.keys()) == sorted(b.keys())
+  for k in a.keys():
+    assert a[k].dims == b[k].dims and a[k].shape == b[k].shape, (k, a[k].dims, b[k].dims)
+    np.testing.assert_array_equal(np.asarray(a[k].values), np.asarray(b[k].values), err_msg=k)
+  for c in ("time", "lat", "lon", "level"):
+    if c in b.coords:
+      np.testing.assert_array_equal(np.asarray(a.coords[c].values), np.asarray(b.coords[c].values))
+
+
+def test_chunked_prediction_runs_the_fused_device_loop_under_a_recognised_stack(setup, caplog):
+  """the REFERENCE's entry point -- rollout.chunked_prediction (utils/rollout.py:326-364) on host
+  Datasets -- around the demo stack InputsAndResiduals(GraphCast) runs DeviceRollout's fused loop underneath:
+  bit-identical to DeviceRollout.run, host Datasets back, same dims / coordinates as the generic loop; a closure
+  around the stack is cross-checked on its first chunk, and one that does something ELSE to the predictions falls
+  back to being called chunk by chunk."""
+  from graphcast_amd import autoregressive, rollout_device
+  model, _ = setup
+  n_steps = 4
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, batch=2, num_target_steps=n_steps, seed=23)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  stack = normalization.InputsAndResiduals(model, std, mean, dstd)
+  roll = rollout_device.DeviceRollout(model, std, mean, dstd)
+  want = roll.to_dataset(roll.run(inputs, template, forcings), template)          # host Dataset of the fused loop
+  with generic_loop():
+    generic = rollout.chunked_prediction(lambda rng, **kw: stack(**kw), None, inputs, template, forcings)
+  # (1) the trusted form: as_predictor_fn keeps the stack visible
+  got = rollout.chunked_prediction(rollout.as_predictor_fn(stack), None, inputs, template, forcings)
+  _equal_datasets(got, want)
+  assert all(isinstance(got[k].data, np.ndarray) for k in got.keys())             # host in -> host out
+  for k in got.keys():                                                            # ... and it is the same rollout
+    assert got[k].dims == generic[k].dims and _rel(got[k].values, generic[k].values) < 2e-5
+  np.testing.assert_array_equal(got.coords["time"].values, generic.coords["time"].values)
+  if "datetime" in generic.coords:
+    np.testing.assert_array_equal(got.coords["datetime"].values, generic.coords["datetime"].values)
+  # (2) a closure around the stack (how the reference's users write predictor_fn): found, cross-checked, fused
+  calls = []
+  def fn(rng, inputs, targets_template, forcings):
+    calls.append(1)
+    return stack(inputs, targets_template, forcings)
+  _equal_datasets(rollout.chunked_prediction(fn, None, inputs, template, forcings), want)
+  assert len(calls) == 1                                                          # the first chunk's cross-check only
+  # (3) a closure that ALTERS the predictions must not be short-circuited
+  calls.clear()
+  def doubled(rng, inputs, targets_template, forcings):
+    calls.append(1)
+    out = stack(inputs, targets_template, forcings)
+    return xarray.Dataset({k: out[k] * np.float32(2.0) for k in out.keys()}, coords=dict(out._coords))
+  with generic_loop():
+    want2 = rollout.chunked_prediction(doubled, None, inputs, template, forcings)
+  calls.clear()
+  got2 = rollout.chunked_prediction(doubled, None, inputs, template, forcings)
+  assert len(calls) == n_steps
+  _equal_datasets(got2, want2)
+  # (4) the reference's full chain with the autoregressive wrapper outermost, two steps per chunk: time-leading
+  #     variables, as that wrapper returns them
+  ar = autoregressive.Predictor(stack)
+  with generic_loop():
+    want4 = rollout.chunked_prediction(lambda rng, **kw: ar(**kw), None, inputs, template, forcings, num_steps_per_chunk=2)
+  got4 = rollout.chunked_prediction(rollout.as_predictor_fn(ar), None, inputs, template, forcings, num_steps_per_chunk=2)
+  for k in got4.keys():
+    assert got4[k].dims == want4[k].dims and got4[k].dims[0] == "time"
+    assert _rel(got4[k].values, want4[k].values) < 2e-5
+    np.testing.assert_array_equal(np.moveaxis(got4[k].values, 0, 1), want[k].values)       # the same bits, time-leading
+  # (5) device-resident inputs: device-backed chunks, nothing crosses PCIe
+  put = lambda ds: synthetic.to_device(ds, "cuda:0")
+  chunks = list(rollout.chunked_prediction_generator(rollout.as_predictor_fn(stack), None, inputs, template, 1, forcings,
+                                                     device_put_fn=put))
+  assert len(chunks) == n_steps and all(c["temperature"].data.is_cuda for c in chunks)
+  for s, c in enumerate(chunks):
+    np.testing.assert_array_equal(c["temperature"].values, want["temperature"].isel(time=slice(s, s + 1)).values)
+  # (6) the switch
+  with generic_loop():
+    calls.clear()
+    rollout.chunked_prediction(fn, None, inputs, template, forcings)
+    assert len(calls) == n_steps
+
+
+def test_fused_rollout_in_the_bfloat16_tier(setup):
+  """rollout.chunked_prediction around the reference's demo chain InputsAndResiduals(Bfloat16Cast(GraphCast)): the
+  fused loop runs the step in the "bf16" arithmetic -- the same bits as DeviceRollout under casting.precision_view --
+  and the model's precision is restored afterwards."""
+  from graphcast_amd import casting, rollout_device
+  model, _ = setup
+  inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, num_target_steps=3, seed=29)
+  mean, std, dstd = synthetic.make_stats(gc.TASK_13)
+  stack = normalization.InputsAndResiduals(casting.Bfloat16Cast(model), std, mean, dstd)
+  with casting.precision_view(model, "bf16"):
+    roll = rollout_device.DeviceRollout(model, std, mean, dstd)
+    want = roll.to_dataset(roll.run(inputs, template, forcings), template)
+  got = rollout.chunked_prediction(lambda rng, **kw: stack(**kw), None, inputs, template, forcings)     # (cross-checked)
+  assert model._precision is None
+  _equal_datasets(got, want)
