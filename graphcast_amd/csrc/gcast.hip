@@ -1470,6 +1470,21 @@ bool half_tile_xcd() {
   return v;
 }
 
+// GCAST_PRIO="g,e,s" (read once): wave priorities of every GC_LAYOUT_HALF launch of the process -- GEMM phases, the other
+// phases, staging waves (include/gcast.h GC_PRIO); a launch that carries its own GC_PRIO bits keeps them.
+int half_prio_flags() {
+  static const int v = [] {
+    const char* e = std::getenv("GCAST_PRIO");
+    int g = GC_PRIO_GEMM_DEFAULT, o = GC_PRIO_OTHER_DEFAULT, st = GC_PRIO_STAGE_DEFAULT;
+    if (e) std::sscanf(e, "%d,%d,%d", &g, &o, &st);
+    return GC_PRIO(g, o, st);
+  }();
+  return v;
+}
+inline void apply_prio(gc_rowmlp_desc& dd) {
+  if (!((dd.flags >> GC_PRIO_SHIFT) & 63)) dd.flags |= half_prio_flags();
+}
+
 template <int MODE, int ONEPASS>
 int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s);
 int half_helpers_default();
@@ -1516,6 +1531,7 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   gc_rowmlp_desc dd = d;
   if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
   if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
+  apply_prio(dd);
   hipLaunchKernelGGL((rowmlp16h_kernel<MODE, ONEPASS>), dim3(grid), dim3(256), lds, s, dd);
   return check_launch("rowmlp16h_kernel");
 }
@@ -1550,6 +1566,7 @@ int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
   gc_rowmlp_desc dd = d;
   if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
   if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
+  apply_prio(dd);
   hipLaunchKernelGGL((rowmlp16d_kernel<MODE, ONEPASS>), dim3(grid), dim3(512), lds, s, dd);
   return check_launch("rowmlp16d_kernel");
 }
@@ -1587,6 +1604,7 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   const int slots = GC_SCRATCH_SLOTS * 4 / NW;        // persistent: 8 / NW workgroups per CU
   gc_rowmlp_desc dd = d;
   if (!tile_queue_pays(dd, tiles, tiles < slots ? tiles : slots)) dd.tile_queue = nullptr;
+  apply_prio(dd);
   hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, dd);
   return check_launch("rowmlpbf_kernel");
 }

@@ -181,6 +181,15 @@ class DeviceRollout:
     if len(np.unique(np.diff(np.asarray(targets_template.coords["time"].values)))) > 1:
       raise ValueError("The targets time coordinates must be evenly spaced")
     model._maybe_init(np.asarray(inputs.coords["lat"].values), np.asarray(inputs.coords["lon"].values))
+    # Host Datasets: every variable is uploaded as the caller holds it, ONCE per rollout (inputs 2 GB, the forcings of
+    # all lead times 20 MB each at 0.25 deg), so that normalisation and stacking below run on the device -- on the host
+    # they cost 4-5 s per 40-step rollout, single-threaded numpy (profiles/r05_s1_*: 246 ms per step through
+    # rollout.chunked_prediction with them, the loop itself 54)
+    if str(dev).startswith("cuda"):
+      if xarray.is_host(inputs):
+        inputs = xarray.to_device(inputs, dev)
+      if xarray.is_host(forcings):
+        forcings = xarray.to_device(forcings, dev)
     self._sizes = dict(inputs.sizes)
     self._build_tables(inputs, targets_template, forcings)
     tb = self._tables

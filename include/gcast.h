@@ -123,6 +123,16 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
 #endif
 #define GC_HELPERS_MIN_ROWS_DEFAULT 65536   /* the plan API / engine.StepEngine ask for GC_WG_HELPERS on launches without
                                              * gather / segment-sum from this many rows on (0: never) */
+/* GC_LAYOUT_HALF: wave issue priority by phase (s_setprio; round 5).  Two waves share a SIMD -- the two workgroups of
+ * a CU, or a multiplying and a staging wave of the eight-wave form -- and the scheduler arbitrates their VALU / MFMA
+ * issue by priority, then age (MI355X_MICROARCH.md "Two waves per SIMD").  Three 2-bit fields: the priority of a wave
+ * inside its GEMM phases, outside them (gather, LayerNorm, segment-sum, residual / store), and of a staging wave.
+ * 0 everywhere = the hardware default.  A speed choice only.  GCAST_PRIO="g,e,s" sets it for a whole process. */
+#define GC_PRIO_SHIFT 16
+#define GC_PRIO(gemm, other, stage) ((((gemm) & 3) | (((other) & 3) << 2) | (((stage) & 3) << 4)) << GC_PRIO_SHIFT)
+#define GC_PRIO_GEMM_DEFAULT 0
+#define GC_PRIO_OTHER_DEFAULT 0
+#define GC_PRIO_STAGE_DEFAULT 0
 #define GC_TILE_XCD 16           /* GC_LAYOUT_HALF: tile -> workgroup map in which each XCD walks a contiguous eighth
                                   * of the launch's tiles (csrc/rowmlp_half.inc).  A speed choice only. */
 

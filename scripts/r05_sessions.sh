@@ -26,5 +26,16 @@ case "$NAME" in
     timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
     timeout 600 python bench.py --mode partition --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_partition_n1.json" 2> "$OUT/bench_partition.err"; echo "partition rc=$?"; show "$OUT/bench_partition_n1.json"
     ;;
+  s2)
+    # Round-5 session 2: wave issue priority by phase (gc_rowmlp_desc.flags GC_PRIO / GCAST_PRIO="gemm,other,stage"):
+    # same-session A/B of the whole step in both arithmetic tiers, two-workgroups-per-CU and helper-wave forms.
+    bash scripts/session.sh bench-ab r05_s2 "GCAST_PRIO=0,0,0" "GCAST_PRIO=1,0,0" "GCAST_PRIO=2,0,0" "GCAST_PRIO=0,1,0" \
+        "GCAST_PRIO=3,0,0" "GCAST_PRIO=0,0,0"
+    bash scripts/session.sh bench-ab r05_s2h "GCAST_HELPERS=1 GCAST_PRIO=0,0,0" "GCAST_HELPERS=1 GCAST_PRIO=1,0,0" \
+        "GCAST_HELPERS=1 GCAST_PRIO=3,0,0" "GCAST_HELPERS=1 GCAST_PRIO=0,0,1"
+    bash scripts/session.sh bench-ab r05_s2b --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 --precision bf16 -- \
+        "GCAST_PRIO=0,0,0" "GCAST_PRIO=1,0,0" "GCAST_PRIO=0,1,0" "GCAST_PRIO=0,0,0"
+    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check > "$OUT/bench_rollout_api.json" 2> "$OUT/bench_rollout_api.err"; echo "bench rc=$?"; show "$OUT/bench_rollout_api.json"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
