@@ -549,8 +549,10 @@ def rollout_api_extra(model, task, lat, lon, n_steps):
 
   consume(template.isel(time=slice(0, 2)), forcings.isel(time=slice(0, 2)))           # warm-up: tables, pinned pages
   ms, n, host, finite = consume(template, forcings)
+  host_s = {k: round(v, 3) for k, v in rollout.last_fused_stats.get("stats", {}).items()}
   closure, fn = fn, rollout.as_predictor_fn(stack)        # the trusted form: no first-chunk cross-check
   ms_trusted, _, _, _ = consume(template, forcings)
+  host_s_trusted = {k: round(v, 3) for k, v in rollout.last_fused_stats.get("stats", {}).items()}
   fn = closure
   os.environ["GCAST_ROLLOUT_FUSED"] = "0"
   try:
@@ -560,7 +562,7 @@ def rollout_api_extra(model, task, lat, lon, n_steps):
     del os.environ["GCAST_ROLLOUT_FUSED"]
   return {"steps": n, "ms_per_step": ms / max(n, 1), "steps_per_second": 1e3 * n / ms, "host_datasets_out": host,
           "finite_sampled": finite, "ms_per_step_as_predictor_fn": ms_trusted / max(n, 1),
-          "generic_loop_ms_per_step": ms_generic / k,
+          "generic_loop_ms_per_step": ms_generic / k, "host_seconds": host_s, "host_seconds_as_predictor_fn": host_s_trusted,
           "what": f"{n_steps} x 6 h steps through rollout.chunked_prediction_generator(lambda around InputsAndResiduals(GraphCast)) on "
                   "HOST Datasets: host wall time incl. upload, first-chunk cross-check and the per-chunk D2H (0.94 GB, "
                   "overlapped); as_predictor_fn = the same with rollout.as_predictor_fn(stack) instead of the closure (no cross-check "

@@ -1472,17 +1472,26 @@ bool half_tile_xcd() {
 
 // GCAST_PRIO="g,e,s" (read once): wave priorities of every GC_LAYOUT_HALF launch of the process -- GEMM phases, the other
 // phases, staging waves (include/gcast.h GC_PRIO); a launch that carries its own GC_PRIO bits keeps them.
-int half_prio_flags() {
-  static const int v = [] {
+// Default (round 5, same-session A/B of the whole 0.25 deg step, profiles/r05_s2_*): GEMM phases at priority 1 in the
+// f16x3 kernels -- processor edge update 19.91 -> 19.43 ms per step, whole step 50.73 -> 50.47 ms; priorities 2 / 3 and
+// a raised priority OUTSIDE the GEMM phases measured within noise of the default, the helper-wave form and the bf16
+// tier do not react at all (their defaults stay 0).
+int half_prio_flags(bool bf16) {
+  static const int v[2] = {[] {
     const char* e = std::getenv("GCAST_PRIO");
     int g = GC_PRIO_GEMM_DEFAULT, o = GC_PRIO_OTHER_DEFAULT, st = GC_PRIO_STAGE_DEFAULT;
     if (e) std::sscanf(e, "%d,%d,%d", &g, &o, &st);
     return GC_PRIO(g, o, st);
-  }();
-  return v;
+  }(), [] {
+    const char* e = std::getenv("GCAST_PRIO");
+    int g = 0, o = 0, st = 0;
+    if (e) std::sscanf(e, "%d,%d,%d", &g, &o, &st);
+    return GC_PRIO(g, o, st);
+  }()};
+  return v[bf16 ? 1 : 0];
 }
-inline void apply_prio(gc_rowmlp_desc& dd) {
-  if (!((dd.flags >> GC_PRIO_SHIFT) & 63)) dd.flags |= half_prio_flags();
+inline void apply_prio(gc_rowmlp_desc& dd, bool bf16 = false) {
+  if (!((dd.flags >> GC_PRIO_SHIFT) & 63)) dd.flags |= half_prio_flags(bf16);
 }
 
 template <int MODE, int ONEPASS>
@@ -1604,7 +1613,7 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   const int slots = GC_SCRATCH_SLOTS * 4 / NW;        // persistent: 8 / NW workgroups per CU
   gc_rowmlp_desc dd = d;
   if (!tile_queue_pays(dd, tiles, tiles < slots ? tiles : slots)) dd.tile_queue = nullptr;
-  apply_prio(dd);
+  apply_prio(dd, true);
   hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, dd);
   return check_launch("rowmlpbf_kernel");
 }

@@ -130,7 +130,7 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, G
  * 0 everywhere = the hardware default.  A speed choice only.  GCAST_PRIO="g,e,s" sets it for a whole process. */
 #define GC_PRIO_SHIFT 16
 #define GC_PRIO(gemm, other, stage) ((((gemm) & 3) | (((other) & 3) << 2) | (((stage) & 3) << 4)) << GC_PRIO_SHIFT)
-#define GC_PRIO_GEMM_DEFAULT 0
+#define GC_PRIO_GEMM_DEFAULT 1      /* (the GC_PREC_F16X3 kernels; GC_PREC_BF16: 0 -- measured, csrc/gcast.hip half_prio_flags) */
 #define GC_PRIO_OTHER_DEFAULT 0
 #define GC_PRIO_STAGE_DEFAULT 0
 #define GC_TILE_XCD 16           /* GC_LAYOUT_HALF: tile -> workgroup map in which each XCD walks a contiguous eighth

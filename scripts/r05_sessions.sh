@@ -37,5 +37,13 @@ case "$NAME" in
         "GCAST_PRIO=0,0,0" "GCAST_PRIO=1,0,0" "GCAST_PRIO=0,1,0" "GCAST_PRIO=0,0,0"
     timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check > "$OUT/bench_rollout_api.json" 2> "$OUT/bench_rollout_api.err"; echo "bench rc=$?"; show "$OUT/bench_rollout_api.json"
     ;;
+  s3)
+    # Round-5 session 3: where the host time of the fused rollout behind rollout.chunked_prediction_generator goes
+    # (rollout_api.host_seconds), with the device-side upload in DeviceRollout._prepare and the sampled cross-check; the
+    # shipped priority default against GCAST_PRIO=0,0,0; the emulated 8-way partition's per-rank time (baseline).
+    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
+    GCAST_PRIO=0,0,0 timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_prio0.json" 2> "$OUT/bench_prio0.err"; echo "bench rc=$?"; show "$OUT/bench_prio0.json"
+    timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8.json" 2>&1 | tail -5
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
