@@ -230,7 +230,7 @@ def main():
   ap.add_argument("--config", default="0.25deg_37L_M6", choices=sorted(CONFIGS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--op-timing-iters", type=int, default=2)
-  ap.add_argument("--precision", default=None, choices=["f16x3", "f32", "bf16gemm", "bf16"],
+  ap.add_argument("--precision", default=None, choices=["f16x3", "f32", "bf16"],
                   help="GEMM arithmetic (include/gcast.h gc_precision); default: engine default")
   ap.add_argument("--no-cross-check", action="store_true",
                   help="skip the full-size f16x3-vs-f32-MFMA agreement check (N = 1 only)")
@@ -361,7 +361,6 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"f16x3": "f32 (3 x f16-split MFMA products, f32 accumulate)", "f32": "f32",
-                  "bf16gemm": "bf16 GEMM operands, f32 accumulate (reduced-precision TIER: not the headline)",
                   "bf16": "bf16 activations + parameters, f32 accumulate = the reference's Bfloat16Cast run "
                           "(reduced-precision TIER: not the headline)"}[precision],
         "data": "synthetic",
@@ -374,7 +373,7 @@ def main():
             "batch_per_gpu": 1},
         "roofline": {
             "bound": "mfma",
-            "kernel": f"{ {'f16x3': 'rowmlp16h_kernel' if getattr(engine, 'half', False) else 'rowmlp16_kernel', 'f32': 'rowmlp_kernel', 'bf16gemm': 'rowmlpb_kernel', 'bf16': 'rowmlpbf_kernel'}[precision] }"
+            "kernel": f"{ {'f16x3': 'rowmlp16h_kernel', 'f32': 'rowmlp_kernel', 'bf16': 'rowmlpbf_kernel'}[precision] }"
                       f"<MLP_LN> stage {dominant}",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,

@@ -14,8 +14,9 @@ _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 MODE_LINEAR, MODE_MLP_LN, MODE_MLP_OUT = 0, 1, 2
 OP_ROWMLP, OP_FIXUP, OP_ZERO, OP_PREP, OP_ADD = 0, 1, 2, 3, 4
-PREC_F32, PREC_F16X3, PREC_BF16_GEMM, PREC_BF16 = 0, 1, 2, 3
-PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16gemm": PREC_BF16_GEMM, "bf16": PREC_BF16}
+PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 3          # (2: the bf16-GEMM-operand tier of rounds 1-4, retired; still the id of
+PREC_BF16_IMAGE = 2                                # the plain bfloat16 weight image in gc_host_pack_weight)
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
 ROWS_F32 = 1                                      # GC_ROWS_F32 (gc_rowmlp_desc.flags)
 W2_NATURAL = 2                                    # GC_W2_NATURAL
 WG_ROWS_64, WG_ROWS_128 = 4, 8                    # GC_WG_ROWS_64 / GC_WG_ROWS_128 (GC_PREC_BF16: pin the rows per workgroup)

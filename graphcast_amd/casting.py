@@ -13,9 +13,8 @@ streams and every aggregation except grid2mesh's (``graphcast.py:215``) are bflo
     in fp32.  That is never less accurate than the reference's run but NOT bit-identical to it
     (XLA's fusion choices and its bfloat16 scatter order cannot be reproduced offline): the tier has
     its own op-by-op oracle (``oracle/gnn.py``, ``ACTIVATIONS = "bf16"``), marked parity-unpinned.
-  * ``Bf16GemmTier`` runs the ``"bf16gemm"`` mode (``GC_PREC_BF16_GEMM``): only the GEMM OPERANDS are
-    rounded to bfloat16, everything between the GEMMs stays fp32.  Sits between the fp32-grade step
-    and ``Bfloat16Cast``; kept for A/B runs.
+  (Rounds 1-4 also carried a ``Bf16GemmTier`` -- only the GEMM operands rounded to bfloat16 -- that the reference does
+  not have; retired in round 5.)
 
 numpy has no bfloat16: on host datasets the inputs are rounded *to bfloat16-representable
 float32 values*; torch-backed (HBM-resident) datasets are rounded through ``torch.bfloat16``.
@@ -28,7 +27,7 @@ from graphcast_amd import packing
 from graphcast_amd import predictor_base
 from graphcast_amd import xarray_lite as xarray
 
-TIER = "bf16gemm"
+TIER = "bf16"
 
 
 def _round_bf16(data):
@@ -64,10 +63,6 @@ def precision_view(predictor, tier):
     inner.set_precision(prev)
 
 
-def bf16_gemm_view(predictor):
-  return precision_view(predictor, TIER)
-
-
 class _Bf16Wrapper(predictor_base.Predictor):
   """Inputs / forcings / predictions rounded to bfloat16 values (reference ``_all_inputs_to_bfloat16``
   :126-134 and the cast back to the targets' dtype :61-65), the wrapped predictor run in `_tier`."""
@@ -95,11 +90,6 @@ class _Bf16Wrapper(predictor_base.Predictor):
     if not self._enabled:
       return self._predictor.loss_and_predictions(inputs, targets, forcings, **kwargs)
     raise NotImplementedError("inference build: training losses are out of scope")
-
-
-class Bf16GemmTier(_Bf16Wrapper):
-  """bfloat16 GEMM operands, fp32 everywhere else (``GC_PREC_BF16_GEMM``)."""
-  _tier = TIER
 
 
 class Bfloat16Cast(_Bf16Wrapper):

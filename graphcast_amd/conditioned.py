@@ -63,7 +63,7 @@ class ConditionedEncoderDecoder(engine.StepEngine):
     precision = precision or engine.DEFAULT_PRECISION
     self.precision, self.prec = precision, nat.PRECISIONS[precision]
     import os
-    self.half = (os.environ.get("GCAST_HALF", engine.DEFAULT_HALF) == "1") and self.prec == nat.PREC_F16X3
+    self.half = self.prec == nat.PREC_F16X3
     self.scratch = None
     # latents come from the caller: every launch that reads rows carries the f16x3 range flag (engine.StepEngine.check_range)
     self.check_all_rows = True

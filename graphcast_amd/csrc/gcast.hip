@@ -33,37 +33,25 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #ifndef GC_SCHED_PIN
 #define GC_SCHED_PIN 1
 #endif
-#ifndef GC_RIDE
-#define GC_RIDE 1        // split-f16 path: memory instructions ride one-per-MFMA (see mma16_group)
-#endif
-#ifndef GC_DMA_LEAD
-#define GC_DMA_LEAD 2    // trailing MFMA groups of a chunk that issue no weight DMA (it must have landed
-#endif                   // by the in-group barrier of the last one)
 #ifndef GC_DMA_ASM
 #define GC_DMA_ASM 1     // LDS-DMA as inline asm (see stage_piece)
-#endif
-#ifndef GC_PIPE
-#define GC_PIPE 2        // split-f16 path: where the per-chunk barrier sits (see mma16_group)
 #endif
 #ifndef GC_ASM_FLUSH
 #define GC_ASM_FLUSH 1   // segment-sum run flush as an inline-asm store (see finish_rows; -1.1 % per launch)
 #endif
-#ifndef GC_TRACE
-#define GC_TRACE 0       // profiling ONLY: rowmlp16 writes phase timestamps of wave 0 to d.partial
-#endif                   // (launches without segment-sum; a profiling library: scripts/probes/build_probe_lib.sh)
 #ifndef GC_EXP
 #define GC_EXP 0         // profiling experiments ONLY on the chunked kernels (results are wrong; round-1 probes):
 #endif                   // bit0 no weight DMA after the prologue, bit1 no fragment reads, bit2 no MFMA,
                          // bit3 never wait for the DMA
 
 // Profiling switches that make a kernel compute WRONG results (GC_EXP: pieces of the work
-// removed) or write timestamps over result buffers (GC_TRACE, GC_H_TRACE) only compile in a build that
+// removed) or write timestamps over result buffers (GC_H_TRACE) only compile in a build that
 // says so: scripts/probes/build_probe_lib.sh passes -DGC_PROFILING_BUILD (scripts/half_probe.py loads such a
 // library NEXT to the product one), the product build
 // (graphcast_amd/_native.py: build) never does, gc_build_info() reports it and the Python binding
 // refuses to load such a library as the product.
-#if (GC_EXP != 0 || GC_TRACE != 0) && !defined(GC_PROFILING_BUILD)
-#error "GC_EXP / GC_TRACE are profiling-only: compile with -DGC_PROFILING_BUILD"
+#if GC_EXP != 0 && !defined(GC_PROFILING_BUILD)
+#error "GC_EXP is profiling-only: compile with -DGC_PROFILING_BUILD"
 #endif
 
 namespace {
@@ -266,200 +254,7 @@ __device__ __forceinline__ void split8(f4 a, f4 b, u4& hi, u4& lo) {
   lo = u4{l0, l1, l2, l3};
 }
 
-// Group T of a chunk = 4 n-blocks = 12 MFMAs (192 issue cycles).  Issue order, pinned by
-// scheduling fences as in the fp32 path:
-//   1. this group's share of the NEXT chunk's LDS-DMA,
-//   2. the four hi.hi MFMAs (their fragments were requested one group ago),
-//   3. the 8 ds_read_b128 of group T+1's fragments,
-//   4. the lo.hi and hi.lo MFMAs, which cover the latency of 3.
-// Every accumulator sees its three dependent MFMAs four issue slots apart, and NOTHING else is
-// issued between the MFMAs of a round: on this chip an instruction wedged between two
-// back-to-back MFMAs costs far more than its own issue slot (measured here: weaving the
-// swish / fp16-split VALU work of the next K step into the stream made the step slower, not
-// faster), so VALU work runs in bursts at chunk boundaries instead.  (A finer weave -- the 80
-// VALU instructions cut into 40 micro-steps of <= 2, one behind each of the first 40 MFMAs,
-// which scripts/ubench/mfma_issue.hip shows to be free in isolation -- measured equal to the
-// burst in the real kernel, within noise, and was dropped for simplicity.)
-//
-// GC_PIPE == 2 (default): the workgroup barrier that publishes the NEXT chunk sits INSIDE the
-// last group, between 2 and 3, and step 3 then requests the next chunk's first fragments: the
-// barrier and the LDS latency hide behind the last 8 MFMAs instead of opening a bubble at the
-// top of every chunk (with 16-cycle MFMAs a chunk is only ~1500 cycles).  All of the next
-// chunk's DMA is issued in the first kGroups-2 groups so that it has landed by then.  Safe with
-// two buffers: every wave has its last fragments of the current buffer in registers before the
-// barrier, and the DMA that overwrites that buffer is only issued after it.
-// GC_PIPE == 1: barrier + first fragment reads at the top of each chunk (the fp32 path's scheme).
-template <int NBLK, int PIECES, int T, bool NEXT>
-__device__ __forceinline__ void mma16_group(f4 (&acc)[kNB], const u4* wb, const u4* wb_next,
-                                            const u4 (&ah)[4], const u4 (&al)[4], u4 (&oh)[4],
-                                            u4 (&ol)[4], u4 bh, u4 bl,
-                                            const float* __restrict__ next_src, float* next_dst,
-                                            int wave, int lane) {
-  constexpr int kGroups = (NBLK + 3) / 4;
-  constexpr int n0 = 4 * T;
-  constexpr int cnt = NBLK - n0 < 4 ? NBLK - n0 : 4;
-  constexpr int kDmaGroups = (GC_PIPE == 2 && kGroups > GC_DMA_LEAD) ? kGroups - GC_DMA_LEAD : kGroups;
-  constexpr int kPpg = (PIECES + kDmaGroups - 1) / kDmaGroups;
-  constexpr bool more = T + 1 < kGroups;
-  constexpr bool cross = !more && NEXT && GC_PIPE == 2;
-  constexpr int cnt2 = more ? (NBLK - n0 - 4 < 4 ? NBLK - n0 - 4 : 4) : 0;
-  static_assert(kPpg <= 4, "at most one DMA piece behind each MFMA of the last round");
-#define GC_FENCE() __builtin_amdgcn_sched_barrier(0)
-#if GC_RIDE
-  // GC_RIDE: every memory instruction of the group rides behind ONE MFMA, fenced there
-  // (scripts/ubench/mfma_issue.hip: eight ds_read_b128 in a burst in front of twelve MFMAs cost
-  // 21.5 cycles per MFMA, one behind each of eight MFMAs 17.3 -- the bare MFMA stream is 17.1):
-  //   round 1  hi.hi MFMA q  +  ds_read of the next group's hi fragment q
-  //   round 2  lo.hi MFMA q  +  ds_read of the next group's lo fragment q
-  //   round 3  hi.lo MFMA q  +  LDS-DMA piece q of the next chunk
-  // Fragment q is thus requested 12 (hi) / 16 (lo) MFMAs before its first use.  In the chunk's
-  // last group the publishing barrier sits after round 1 and rounds 2 / 3 carry the NEXT chunk's
-  // first fragment reads.
-  u4 nh[4], nl[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    nh[q] = ah[q];
-    nl[q] = al[q];
-  }
-  if constexpr (cross) {
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this group's fragments, in one wait
-    GC_FENCE();
-#pragma unroll
-    for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
-    GC_FENCE();
-    dma_wait();
-    __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cnt) acc[n0 + q] = mfma32h(ah[q], bl, acc[n0 + q]);
-      nh[q] = wb_next[q * 128];
-      GC_FENCE();
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cnt) acc[n0 + q] = mfma32h(al[q], bh, acc[n0 + q]);
-      nl[q] = wb_next[q * 128 + 64];
-      GC_FENCE();
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cnt) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
-      if (q < cnt2 && !(GC_EXP & 2)) nh[q] = wb[(n0 + 4 + q) * 128];
-      GC_FENCE();
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cnt) acc[n0 + q] = mfma32h(ah[q], bl, acc[n0 + q]);
-      if (q < cnt2 && !(GC_EXP & 2)) nl[q] = wb[(n0 + 4 + q) * 128 + 64];
-      GC_FENCE();
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cnt) acc[n0 + q] = mfma32h(al[q], bh, acc[n0 + q]);
-      if (!(GC_EXP & 1) && q < kPpg && T * kPpg + q < PIECES)
-        stage_piece(next_src, next_dst, T * kPpg + q, wave, lane);
-      GC_FENCE();
-    }
-  }
-#else
-#pragma unroll
-  for (int p = 0; p < kPpg; ++p) {
-    if (!(GC_EXP & 1) && T * kPpg + p < PIECES) stage_piece(next_src, next_dst, T * kPpg + p, wave, lane);
-  }
-  GC_FENCE();
-  u4 nh[4], nl[4];
-  // With the DMA out of the compiler's sight (GC_DMA_ASM) the next group's fragments are
-  // requested BEFORE this group's MFMAs and stay in flight behind all twelve of them
-  // (s_waitcnt lgkmcnt(8) in front of the first MFMA); otherwise after the first four.
-  constexpr bool early = GC_DMA_ASM && !cross;
-  if constexpr (early) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cnt2 && !(GC_EXP & 2)) {
-        nh[q] = wb[(n0 + 4 + q) * 128];
-        nl[q] = wb[(n0 + 4 + q) * 128 + 64];
-      } else {
-        nh[q] = ah[q];
-        nl[q] = al[q];
-      }
-    }
-    constexpr int kInFlight = 2 * cnt2;
-    __builtin_amdgcn_s_waitcnt(0xC07F | (kInFlight << 8));    // vmcnt(63) expcnt(7) lgkmcnt(kInFlight)
-    GC_FENCE();
-  }
-  if constexpr (GC_DMA_ASM && !early) {
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this group's fragments, in one wait
-    GC_FENCE();
-  }
-#pragma unroll
-  for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bh, acc[n0 + q]);
-  GC_FENCE();
-  if constexpr (cross) {
-    dma_wait();
-    __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      nh[q] = wb_next[q * 128];
-      nl[q] = wb_next[q * 128 + 64];
-    }
-  } else if constexpr (!early) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cnt2 && !(GC_EXP & 2)) {
-        nh[q] = wb[(n0 + 4 + q) * 128];
-        nl[q] = wb[(n0 + 4 + q) * 128 + 64];
-      } else {
-        nh[q] = ah[q];
-        nl[q] = al[q];
-      }
-    }
-  }
-  GC_FENCE();
-#pragma unroll
-  for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(ah[q], bl, acc[n0 + q]);
-#pragma unroll
-  for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32h(al[q], bh, acc[n0 + q]);
-  GC_FENCE();
-#endif
-  if constexpr (more) {
-    mma16_group<NBLK, PIECES, T + 1, NEXT>(acc, wb, wb_next, nh, nl, oh, ol, bh, bl, next_src,
-                                           next_dst, wave, lane);
-  } else if constexpr (cross) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      oh[q] = nh[q];
-      ol[q] = nl[q];
-    }
-  }
-}
-
-// The first four n-blocks' fragments of the chunk image at `wbuf`.
-__device__ __forceinline__ void load_first_frags(const float* wbuf, int lane, u4 (&fh)[4], u4 (&fl)[4]) {
-  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    fh[q] = wb[q * 128];
-    fl[q] = wb[q * 128 + 64];
-  }
-}
-
-// acc[nb] += W-chunk(32 k) . B for nb < NBLK.  `wbuf` = the chunk's LDS image, (bh, bl) the split
-// B operand; PIECES 1 KiB-per-wave pieces of the next chunk are DMA'd to `wnext` meanwhile.
-// (fh, fl): in = this chunk's first fragments; out (GC_PIPE == 2, NEXT) = the next chunk's.
-template <int NBLK, int PIECES, bool NEXT>
-__device__ __forceinline__ void mma16_chunk(f4 (&acc)[kNB], const float* wbuf, float* wnext,
-                                            u4 (&fh)[4], u4 (&fl)[4], u4 bh, u4 bl,
-                                            const float* __restrict__ next_src, int wave, int lane) {
-  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
-  const u4* wbn = reinterpret_cast<const u4*>(wnext) + lane;
-  if (GC_PIPE == 1) {
-    dma_wait();
-    __syncthreads();      // this chunk landed; the previous chunk's readers are done
-    load_first_frags(wbuf, lane, fh, fl);
-  }
-  mma16_group<NBLK, PIECES, 0, NEXT>(acc, wb, wbn, fh, fl, fh, fl, bh, bl, next_src, wnext, wave, lane);
-}
+#define GC_FENCE() __builtin_amdgcn_sched_barrier(0)      // pins the issue order of the MFMA / memory weave (rowmlp_half.inc)
 
 __device__ __forceinline__ float swish1(float x) {
   // x * sigmoid(x); __expf/fast reciprocal are ~1-2 ulp, far inside the 1e-4 budget.
@@ -753,247 +548,13 @@ __global__ __launch_bounds__(256, 1) void rowmlp_kernel(const gc_rowmlp_desc d) 
   finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
 }
 
-#if GC_TRACE
-#define GC_MARK(k)                                                                              \
-  do {                                                                                          \
-    if (!d.seg && d.partial && threadIdx.x == 0) {                                               \
-      reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
-    }                                                                                           \
-  } while (0)
-#else
-#define GC_MARK(k) do { } while (0)
-#endif
-
-// ---- GC_PREC_F16X3 ----------------------------------------------------------------------
-// Per-lane row pointers of the layer-1 addends (nullptr = absent); pair p = n-blocks 2p, 2p+1.
-// An absent addend reads this all-zero row instead of branching: the chunk body stays one basic
-// block with a fixed instruction stream.
+// An all-zero row: what an absent addend source reads in the kernels that take it unconditionally.
 __device__ float g_zero_row[kD];
 
-struct AddendRows {
-  const float* dd;
-  const float* g0;
-  const float* g1;
-  __device__ __forceinline__ void issue(int p, f4 (&t)[6]) const {
-    const int o = 32 * p;
-    t[0] = *reinterpret_cast<const f4*>(dd + o);
-    t[1] = *reinterpret_cast<const f4*>(dd + o + 16);
-    t[2] = *reinterpret_cast<const f4*>(g0 + o);
-    t[3] = *reinterpret_cast<const f4*>(g0 + o + 16);
-    t[4] = *reinterpret_cast<const f4*>(g1 + o);
-    t[5] = *reinterpret_cast<const f4*>(g1 + o + 16);
-  }
-};
-
-__device__ __forceinline__ void sum_pair(const f4 (&t)[6], f4& a, f4& b) {
-  a = t[0] + (t[2] + t[4]);
-  b = t[1] + (t[3] + t[5]);
-}
-
-__device__ __forceinline__ float swish1(float x);
-
-// Two pre-activation n-blocks -> the split B operand of one layer-2 K step (swish, then hi/lo
-// halves): one VALU burst per K step.
-struct SwishSplitPair {
-  f4 za, zb;
-  unsigned h[4], l[4];
-  __device__ __forceinline__ void all() {
-    split2(swish1(za.x), swish1(za.y), h[0], l[0]);
-    split2(swish1(za.z), swish1(za.w), h[1], l[1]);
-    split2(swish1(zb.x), swish1(zb.y), h[2], l[2]);
-    split2(swish1(zb.z), swish1(zb.w), h[3], l[3]);
-  }
-};
-
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void rowmlp16_kernel(const gc_rowmlp_desc d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool kLinear = MODE == GC_MODE_LINEAR;
-  constexpr int NP2 = MODE == GC_MODE_MLP_OUT ? 256 : 512;
-  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
-  constexpr int kPieces1 = 512 / 32;       // 1 KiB-per-wave DMA pieces of a layer-1 chunk
-  constexpr int kPieces2 = NP2 / 32;
-  constexpr int kPairs = kNB / 2;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int i = lane & 15;
-  const int g = lane >> 4;
-  const int tile = blockIdx.x;
-  const int row = tile * GC_TILE_ROWS + wave * 16 + i;
-  const int rowc = row < d.n_rows ? row : d.n_rows - 1;
-  const int col0 = 4 * g;
-  const float* w1p = static_cast<const float*>(d.w1p);   // opaque 64 KiB chunks
-  const float* w2p = static_cast<const float*>(d.w2p);
-
-  const int n1 = (d.k0 + d.k1) >> 5;
-  const int n1a = d.k0 >> 5;
-  int q = 0;
-  GC_MARK(0);
-#if GC_TRACE
-  if (!d.seg && d.partial && threadIdx.x == 0) {
-    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
-    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 9] = __smid();
-  }
-#endif
-
-  if (n1 > 0) {
-    stage_chunk<512>(w1p, smem, tid);
-  } else if (!kLinear) {
-    stage_chunk<NP2>(w2p, smem, tid);
-  }
-
-  // The addends b1 + d[row] + g0[idx0[row]] + g1[idx1[row]] are NOT loaded up front: a 64-row
-  // tile of them is up to 384 KiB, a phase of its own at the f16 rate.  They are streamed one
-  // n-block pair per chunk behind the MFMAs (staged in `t` one chunk, summed into `add` the next).
-  const float* b1row = (d.b1 ? d.b1 : g_zero_row) + col0;
-  AddendRows ar;
-  ar.dd = (d.d ? d.d + (size_t)rowc * d.ldd : g_zero_row) + col0;
-  ar.g0 = g_zero_row + col0;
-  ar.g1 = g_zero_row + col0;
-  if (d.g0) {
-    int ix = d.idx0[rowc];
-    ix = ix < 0 ? 0 : ix;
-    ar.g0 = d.g0 + (size_t)ix * kD + col0;
-  }
-  if (d.g1) {
-    int ix = d.idx1[rowc];
-    ix = ix < 0 ? 0 : ix;
-    ar.g1 = d.g1 + (size_t)ix * kD + col0;
-  }
-
-  // The accumulators start from the bias (in the weights' scaled space); the per-row addends are
-  // streamed behind layer 2 (below).
-  f4 acc[kNB];
-#pragma unroll
-  for (int nb = 0; nb < kNB; ++nb) acc[nb] = d.w1_scale * *reinterpret_cast<const f4*>(b1row + nb * 16);
-  f4 t0[6];               // addend staging: loads of one n-block pair in flight behind the MFMAs
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-  u4 fh[4], fl[4];        // fragments of the next four n-blocks, carried across chunks
-  if (GC_PIPE == 2) {
-    dma_wait();
-    __syncthreads();      // the chunk staged in the prologue
-    load_first_frags(smem, lane, fh, fl);
-  }
-  GC_MARK(1);
-  float* const buf0 = smem;
-  float* const buf1 = smem + kBufFloats;
-  const float inv1 = 1.0f / d.w1_scale;         // exact: powers of two
-  const float inv2 = 1.0f / d.w2_scale;
-
-  // ---- layer 1: the lane's 8 consecutive k of its row per chunk, split in registers ----
-  if (n1 > 0) {
-    const float* arow0 = d.a0 + (size_t)rowc * d.lda0 + 8 * g;
-    const float* arow1 = d.k1 ? d.a1 + (size_t)rowc * d.lda1 + 8 * g : arow0;
-    f4 xc0, xc1, xn0, xn1;
-    {
-      const float* p = n1a > 0 ? arow0 : arow1;
-      xc0 = *reinterpret_cast<const f4*>(p);
-      xc1 = *reinterpret_cast<const f4*>(p + 4);
-    }
-    xn0 = xc0;
-    xn1 = xc1;
-    u4 bh, bl;
-    for (int c = 0; c + 1 < n1; ++c) {
-      {
-        const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
-        xn0 = *reinterpret_cast<const f4*>(p);
-        xn1 = *reinterpret_cast<const f4*>(p + 4);
-      }
-      split8(xc0, xc1, bh, bl);
-      mma16_chunk<kNB, kPieces1, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl,
-                                       bh, bl, w1p + (size_t)(c + 1) * kBufFloats, wave_u, lane);
-      xc0 = xn0;
-      xc1 = xn1;
-      ++q;
-    }
-    split8(xc0, xc1, bh, bl);
-    if (kLinear) {
-      mma16_chunk<kNB, 0, false>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl, bh, bl,
-                                 nullptr, wave_u, lane);
-    } else {
-      mma16_chunk<kNB, kPieces2, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl,
-                                       bh, bl, w2p, wave_u, lane);
-    }
-    ++q;
-#pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) acc[nb] *= inv1;
-  }
-  GC_MARK(2);
-
-  if (kLinear) {
-    if (d.d || d.g0 || d.g1) {   // per-row addends of a LINEAR launch (load-time folding only): eager
-#pragma unroll
-      for (int p = 0; p < kPairs; ++p) {
-        f4 a, b;
-        ar.issue(p, t0);
-        sum_pair(t0, a, b);
-        acc[2 * p] += a;
-        acc[2 * p + 1] += b;
-        __builtin_amdgcn_sched_barrier(0);     // (keeps the 128 loads from being hoisted together)
-      }
-    }
-    store_linear(acc, d, row, col0);
-    return;
-  }
-
-  // ---- layer 2.  K step cc consumes hidden blocks (2cc, 2cc+1) = swish(acc + addends).  The
-  // addends of pair cc+2 are requested at the top of step cc and summed at the top of step cc+1,
-  // so their latency hides behind a whole K step of MFMAs; the swish + fp16 split of pair cc+1
-  // runs as ONE VALU burst at the top of step cc (instructions wedged between back-to-back
-  // MFMAs cost far more than they hide: MI355X_MICROARCH.md, "one extra issue slot").
-  SwishSplitPair sw;
-  ar.issue(0, t0);
-  sum_pair(t0, sw.za, sw.zb);
-  ar.issue(1, t0);
-  sw.za += acc[0];
-  sw.zb += acc[1];
-  sw.all();
-  GC_MARK(3);
-  f4 o2[kNB];
-#pragma unroll
-  for (int nb = 0; nb < NB2; ++nb) o2[nb] = d.w2_scale * *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
-#pragma unroll
-  for (int cc = 0; cc < kPairs; ++cc) {
-    const u4 bh = u4{sw.h[0], sw.h[1], sw.h[2], sw.h[3]};
-    const u4 bl = u4{sw.l[0], sw.l[1], sw.l[2], sw.l[3]};
-    if (cc + 1 < kPairs) {
-      sum_pair(t0, sw.za, sw.zb);
-      sw.za += acc[2 * cc + 2];
-      sw.zb += acc[2 * cc + 3];
-      if (cc + 2 < kPairs) ar.issue(cc + 2, t0);
-      sw.all();
-      mma16_chunk<NB2, kPieces2, true>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl,
-                                       bh, bl, w2p + (size_t)(cc + 1) * (8 * NP2 * 4), wave_u, lane);
-    } else {
-      mma16_chunk<NB2, 0, false>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fh, fl, bh, bl,
-                                 nullptr, wave_u, lane);
-    }
-    ++q;
-  }
-  GC_MARK(4);
-#pragma unroll
-  for (int nb = 0; nb < NB2; ++nb) o2[nb] *= inv2;
-  finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
-  GC_MARK(5);
-#if GC_TRACE
-  if (!d.seg && d.partial && threadIdx.x == 0)
-    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
-#endif
-}
 
 #include "rowmlp_half.inc"
 
-// ---- GC_PREC_BF16_GEMM -----------------------------------------------------------------------
-// A reduced-precision tier: GEMM operands rounded to bfloat16 (round to nearest even), ONE
-// v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation.  Everything between the GEMMs (bias,
-// addends, swish, LayerNorm, residual, segment-sum) stays fp32 -- so this is neither the
-// fp32-tolerance path nor the numerics of the reference's Bfloat16Cast (utils/casting.py:45-65: all
-// activations in bfloat16, not built); it is checked against an oracle that rounds the same operands.
-// Same register-chained structure as the split-f16 kernel, half the LDS image (no lo halves),
-// groups of eight n-blocks so that eight MFMAs still cover the next group's fragment reads.
+// ---- bfloat16 MFMA / packing helpers of the GC_PREC_BF16 tier (rowmlp_bf16.inc) --------------------------------
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -1010,262 +571,6 @@ __device__ __forceinline__ unsigned pack2bf(float a, float b) {     // v_cvt_pk_
 
 __device__ __forceinline__ u4 pack8bf(f4 a, f4 b) {
   return u4{pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w)};
-}
-
-__device__ __forceinline__ float swish1(float x);
-
-__device__ __forceinline__ u4 swish_pack8bf(f4 a, f4 b) {
-  return u4{pack2bf(swish1(a.x), swish1(a.y)), pack2bf(swish1(a.z), swish1(a.w)),
-            pack2bf(swish1(b.x), swish1(b.y)), pack2bf(swish1(b.z), swish1(b.w))};
-}
-
-__device__ __forceinline__ void loadb_first_frags(const float* wbuf, int lane, u4 (&fa)[8]) {
-  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) fa[q] = wb[q * 64];
-}
-
-// Group T = eight n-blocks = eight MFMAs; the next group's eight fragment reads are requested
-// first and stay in flight behind them; the last group of a chunk carries the publishing
-// barrier and the next chunk's first fragment reads between its two halves.
-template <int NBLK, int PIECES, int T, bool NEXT>
-__device__ __forceinline__ void mmab_group(f4 (&acc)[kNB], const u4* wb, const u4* wb_next,
-                                           const u4 (&a)[8], u4 (&o)[8], u4 b,
-                                           const float* __restrict__ next_src, float* next_dst,
-                                           int wave, int lane) {
-  constexpr int kGroups = (NBLK + 7) / 8;
-  constexpr int n0 = 8 * T;
-  constexpr int cnt = NBLK - n0 < 8 ? NBLK - n0 : 8;
-  constexpr int kDmaGroups = kGroups > 2 ? kGroups - 2 : 1;
-  constexpr int kPpg = (PIECES + kDmaGroups - 1) / kDmaGroups;
-  constexpr bool more = T + 1 < kGroups;
-  constexpr bool cross = !more && NEXT;
-  constexpr int cnt2 = more ? (NBLK - n0 - 8 < 8 ? NBLK - n0 - 8 : 8) : 0;
-  if constexpr (T < kDmaGroups) {
-#pragma unroll
-    for (int p = 0; p < kPpg; ++p) {
-      if (T * kPpg + p < PIECES) stage_piece(next_src, next_dst, T * kPpg + p, wave, lane);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  u4 n[8];
-  if constexpr (!cross) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) n[q] = q < cnt2 ? wb[(n0 + 8 + q) * 64] : a[q];
-    __builtin_amdgcn_s_waitcnt(0xC07F | (cnt2 << 8));      // this group's fragments have landed
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < cnt; ++q) acc[n0 + q] = mfma32b(a[q], b, acc[n0 + q]);
-    __builtin_amdgcn_sched_barrier(0);
-  } else {
-    constexpr int half = (cnt + 1) / 2;
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < half; ++q) acc[n0 + q] = mfma32b(a[q], b, acc[n0 + q]);
-    __builtin_amdgcn_sched_barrier(0);
-    dma_wait();
-    __syncthreads();      // next chunk landed for everyone; everyone holds its last fragments
-#pragma unroll
-    for (int q = 0; q < 8; ++q) n[q] = wb_next[q * 64];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = half; q < cnt; ++q) acc[n0 + q] = mfma32b(a[q], b, acc[n0 + q]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if constexpr (more) {
-    mmab_group<NBLK, PIECES, T + 1, NEXT>(acc, wb, wb_next, n, o, b, next_src, next_dst, wave, lane);
-  } else if constexpr (cross) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = n[q];
-  }
-}
-
-template <int NBLK, int PIECES, bool NEXT>
-__device__ __forceinline__ void mmab_chunk(f4 (&acc)[kNB], const float* wbuf, float* wnext, u4 (&fa)[8],
-                                           u4 b, const float* __restrict__ next_src, int wave, int lane) {
-  const u4* wb = reinterpret_cast<const u4*>(wbuf) + lane;
-  const u4* wbn = reinterpret_cast<const u4*>(wnext) + lane;
-  mmab_group<NBLK, PIECES, 0, NEXT>(acc, wb, wbn, fa, fa, b, next_src, wnext, wave, lane);
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void rowmlpb_kernel(const gc_rowmlp_desc d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool kLinear = MODE == GC_MODE_LINEAR;
-  constexpr int NP2 = MODE == GC_MODE_MLP_OUT ? 256 : 512;
-  constexpr int NB2 = MODE == GC_MODE_MLP_OUT ? 15 : 32;
-  constexpr int kPieces1 = 512 / 64;       // 1 KiB-per-wave DMA pieces of a 32 KiB layer-1 chunk
-  constexpr int kPieces2 = NP2 / 64;
-  constexpr int kChunk1 = 512 * 16;        // floats per packed K chunk (bf16: NP * 64 bytes)
-  constexpr int kChunk2 = NP2 * 16;
-  constexpr int kPairs = kNB / 2;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int i = lane & 15;
-  const int g = lane >> 4;
-  const int tile = blockIdx.x;
-  const int row = tile * GC_TILE_ROWS + wave * 16 + i;
-  const int rowc = row < d.n_rows ? row : d.n_rows - 1;
-  const int col0 = 4 * g;
-  const float* w1p = static_cast<const float*>(d.w1p);   // opaque 64 KiB chunks
-  const float* w2p = static_cast<const float*>(d.w2p);
-
-  const int n1 = (d.k0 + d.k1) >> 5;
-  const int n1a = d.k0 >> 5;
-  int q = 0;
-  GC_MARK(0);
-#if GC_TRACE
-  if (!d.seg && d.partial && threadIdx.x == 0) {
-    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
-    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 9] = __smid();
-  }
-#endif
-
-  if (n1 > 0) {
-    stage_chunk<256>(w1p, smem, tid);
-  } else if (!kLinear) {
-    stage_chunk<NP2 / 2>(w2p, smem, tid);
-  }
-
-  // The addends b1 + d[row] + g0[idx0[row]] + g1[idx1[row]] are NOT loaded up front: a 64-row
-  // tile of them is up to 384 KiB, a phase of its own at the f16 rate.  They are streamed one
-  // n-block pair per chunk behind the MFMAs (staged in `t` one chunk, summed into `add` the next).
-  const float* b1row = (d.b1 ? d.b1 : g_zero_row) + col0;
-  AddendRows ar;
-  ar.dd = (d.d ? d.d + (size_t)rowc * d.ldd : g_zero_row) + col0;
-  ar.g0 = g_zero_row + col0;
-  ar.g1 = g_zero_row + col0;
-  if (d.g0) {
-    int ix = d.idx0[rowc];
-    ix = ix < 0 ? 0 : ix;
-    ar.g0 = d.g0 + (size_t)ix * kD + col0;
-  }
-  if (d.g1) {
-    int ix = d.idx1[rowc];
-    ix = ix < 0 ? 0 : ix;
-    ar.g1 = d.g1 + (size_t)ix * kD + col0;
-  }
-
-  // The accumulators start from the bias (in the weights' scaled space); the per-row addends are
-  // streamed behind layer 2 (below).
-  f4 acc[kNB];
-#pragma unroll
-  for (int nb = 0; nb < kNB; ++nb) acc[nb] = d.w1_scale * *reinterpret_cast<const f4*>(b1row + nb * 16);
-  f4 t0[6];               // addend staging: loads of one n-block pair in flight behind the MFMAs
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-  u4 fa[8];               // fragments of the next eight n-blocks, carried across chunks
-  {
-    dma_wait();
-    __syncthreads();      // the chunk staged in the prologue
-    loadb_first_frags(smem, lane, fa);
-  }
-  GC_MARK(1);
-  float* const buf0 = smem;
-  float* const buf1 = smem + kBufFloats;
-  const float inv1 = 1.0f / d.w1_scale;         // exact: powers of two
-  const float inv2 = 1.0f / d.w2_scale;
-
-  // ---- layer 1: the lane's 8 consecutive k of its row per chunk, split in registers ----
-  if (n1 > 0) {
-    const float* arow0 = d.a0 + (size_t)rowc * d.lda0 + 8 * g;
-    const float* arow1 = d.k1 ? d.a1 + (size_t)rowc * d.lda1 + 8 * g : arow0;
-    f4 xc0, xc1, xn0, xn1;
-    {
-      const float* p = n1a > 0 ? arow0 : arow1;
-      xc0 = *reinterpret_cast<const f4*>(p);
-      xc1 = *reinterpret_cast<const f4*>(p + 4);
-    }
-    xn0 = xc0;
-    xn1 = xc1;
-    u4 bb;
-    for (int c = 0; c + 1 < n1; ++c) {
-      {
-        const float* p = (c + 1 < n1a) ? arow0 + (c + 1) * 32 : arow1 + (c + 1 - n1a) * 32;
-        xn0 = *reinterpret_cast<const f4*>(p);
-        xn1 = *reinterpret_cast<const f4*>(p + 4);
-      }
-      bb = pack8bf(xc0, xc1);
-      mmab_chunk<kNB, kPieces1, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb, w1p + (size_t)(c + 1) * kChunk1, wave_u, lane);
-      xc0 = xn0;
-      xc1 = xn1;
-      ++q;
-    }
-    bb = pack8bf(xc0, xc1);
-    if (kLinear) {
-      mmab_chunk<kNB, 0, false>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb,
-                                 nullptr, wave_u, lane);
-    } else {
-      mmab_chunk<kNB, kPieces2, true>(acc, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb, w2p, wave_u, lane);
-    }
-    ++q;
-#pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) acc[nb] *= inv1;
-  }
-  GC_MARK(2);
-
-  if (kLinear) {
-    if (d.d || d.g0 || d.g1) {   // per-row addends of a LINEAR launch (load-time folding only): eager
-#pragma unroll
-      for (int p = 0; p < kPairs; ++p) {
-        f4 a, b;
-        ar.issue(p, t0);
-        sum_pair(t0, a, b);
-        acc[2 * p] += a;
-        acc[2 * p + 1] += b;
-        __builtin_amdgcn_sched_barrier(0);     // (keeps the 128 loads from being hoisted together)
-      }
-    }
-    store_linear(acc, d, row, col0);
-    return;
-  }
-
-  // ---- layer 2.  K step cc consumes hidden blocks (2cc, 2cc+1) = swish(acc + addends).  The
-  // addends of pair cc+2 are requested at the top of step cc and summed at the top of step cc+1,
-  // so their latency hides behind a whole K step of MFMAs; the swish + fp16 split of pair cc+1
-  // runs as ONE VALU burst at the top of step cc (instructions wedged between back-to-back
-  // MFMAs cost far more than they hide: MI355X_MICROARCH.md, "one extra issue slot").
-  u4 sw;
-  ar.issue(0, t0);
-  {
-    f4 za, zb;
-    sum_pair(t0, za, zb);
-    ar.issue(1, t0);
-    sw = swish_pack8bf(za + acc[0], zb + acc[1]);
-  }
-  GC_MARK(3);
-  f4 o2[kNB];
-#pragma unroll
-  for (int nb = 0; nb < NB2; ++nb) o2[nb] = d.w2_scale * *reinterpret_cast<const f4*>(d.b2 + nb * 16 + col0);
-#pragma unroll
-  for (int cc = 0; cc < kPairs; ++cc) {
-    const u4 bb2 = sw;
-    if (cc + 1 < kPairs) {
-      f4 za, zb;
-      sum_pair(t0, za, zb);
-      za += acc[2 * cc + 2];
-      zb += acc[2 * cc + 3];
-      if (cc + 2 < kPairs) ar.issue(cc + 2, t0);
-      sw = swish_pack8bf(za, zb);
-      mmab_chunk<NB2, kPieces2, true>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb2, w2p + (size_t)(cc + 1) * kChunk2, wave_u, lane);
-    } else {
-      mmab_chunk<NB2, 0, false>(o2, (q & 1) ? buf1 : buf0, (q & 1) ? buf0 : buf1, fa, bb2,
-                                 nullptr, wave_u, lane);
-    }
-    ++q;
-  }
-  GC_MARK(4);
-#pragma unroll
-  for (int nb = 0; nb < NB2; ++nb) o2[nb] *= inv2;
-  finish_rows<MODE>(o2, d, smem, tile, row, wave, i, col0, tid);
-  GC_MARK(5);
-#if GC_TRACE
-  if (!d.seg && d.partial && threadIdx.x == 0)
-    reinterpret_cast<long long*>(d.partial)[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
-#endif
 }
 
 #include "rowmlp_bf16.inc"
@@ -1421,31 +726,24 @@ int check_launch(const char* what) {
   return 0;
 }
 
-bool g_attr_set[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
+bool g_attr_set[3] = {false, false, false};
 
+// GC_LAYOUT_CHUNKED = GC_PREC_F32: the exact-fp32 kernel (round 1's formulation; the chunked GC_PREC_F16X3 kernel and
+// the GC_PREC_BF16_GEMM tier that shared it were retired in round 5).
 template <int MODE>
 int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = kLdsFloats * sizeof(float);
-  const int split = d.prec;      // 0 f32, 1 f16x3, 2 bf16
-  if (!g_attr_set[split][MODE]) {
-    const void* fn = split == GC_PREC_F16X3 ? reinterpret_cast<const void*>(&rowmlp16_kernel<MODE>)
-                     : split == GC_PREC_BF16_GEMM ? reinterpret_cast<const void*>(&rowmlpb_kernel<MODE>)
-                                             : reinterpret_cast<const void*>(&rowmlp_kernel<MODE>);
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!g_attr_set[MODE]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp_kernel<MODE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
       return GC_ELAUNCH;
     }
-    g_attr_set[split][MODE] = true;
+    g_attr_set[MODE] = true;
   }
   const int tiles = (d.n_rows + GC_TILE_ROWS - 1) / GC_TILE_ROWS;
-  if (split == GC_PREC_F16X3) {
-    hipLaunchKernelGGL(rowmlp16_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
-  } else if (split == GC_PREC_BF16_GEMM) {
-    hipLaunchKernelGGL(rowmlpb_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
-  } else {
-    hipLaunchKernelGGL(rowmlp_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
-  }
+  hipLaunchKernelGGL(rowmlp_kernel<MODE>, dim3(tiles), dim3(256), lds, s, d);
   return check_launch("rowmlp_kernel");
 }
 
@@ -1706,10 +1004,13 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
     return fail(GC_EINVAL, "gc_rowmlp: weight scales are not a GC_PREC_F32 feature");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.n_rows <= 0) return fail(GC_EINVAL, "gc_rowmlp: n_rows must be positive");
-  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3 && d.prec != GC_PREC_BF16_GEMM)   // (GC_PREC_BF16: above)
+  if (d.prec != GC_PREC_F32 && d.prec != GC_PREC_F16X3)   // (GC_PREC_BF16: above; 2 = the retired GC_PREC_BF16_GEMM tier)
     return fail(GC_EINVAL, "gc_rowmlp: unknown precision");
   if (d.layout != GC_LAYOUT_CHUNKED && d.layout != GC_LAYOUT_HALF)
     return fail(GC_EINVAL, "gc_rowmlp: unknown weight layout");
+  if ((d.prec == GC_PREC_F16X3) != (d.layout == GC_LAYOUT_HALF))
+    return fail(GC_EINVAL, "gc_rowmlp: GC_PREC_F16X3 runs in GC_LAYOUT_HALF, GC_PREC_F32 in GC_LAYOUT_CHUNKED (the chunked f16x3 "
+                           "kernel of rounds 1-4 was retired)");
   if (d.layout == GC_LAYOUT_HALF) {
     if (d.prec != GC_PREC_F16X3) return fail(GC_EINVAL, "gc_rowmlp: GC_LAYOUT_HALF is built for GC_PREC_F16X3 only");
     if (d.mode == GC_MODE_MLP_LN && !(d.flags & GC_W2_NATURAL) && (!d.scratch || !aligned16(d.scratch)))
@@ -1959,8 +1260,8 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR2(x) #x
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
-  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;tiers=bf16gemm|bf16(Bfloat16Cast);"
-         "layouts=chunked|half(2wg/cu,persistent,chain)|half+helpers(8 waves,1wg/cu);pipe=" GC_STR(GC_PIPE) ";ring=4x16k"
+  return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;tiers=bf16(Bfloat16Cast);"
+         "layouts=chunked(f32)|half(f16x3: 2wg/cu,persistent,chain)|half+helpers(8 waves,1wg/cu);ring=4x16k"
          ";helpers_default=" GC_STR(GC_HELPERS_DEFAULT)
 #ifdef GC_SRC_HASH
          ";src=" GC_SRC_HASH

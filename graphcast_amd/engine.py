@@ -31,12 +31,10 @@ D = packing.LATENT
 
 # Arithmetic of the GEMMs (include/gcast.h `gc_precision`): "f16x3" = fp32 operands split into
 # two halves in registers, three f16 MFMAs per product, fp32 accumulation (fp32-grade results);
-# "f32" = exact fp32 MFMA; "bf16gemm" = a reduced-precision tier (GEMM operands rounded to bfloat16,
-# fp32 everywhere else; NOT within the fp32 tolerance and NOT the numerics of the reference's
-# Bfloat16Cast, see casting.py).  Overridable with
-# GCAST_PRECISION.
+# "f32" = exact fp32 MFMA (the chunked round-1 kernel: bench.py's cross-check); "bf16" = the reference's Bfloat16Cast
+# run (casting.py).  Overridable with GCAST_PRECISION.  (The chunked f16x3 kernel -- GCAST_HALF=0 -- and the
+# "bf16gemm" operand-rounding tier of rounds 1-4 were retired in round 5: f16x3 IS the half-N formulation.)
 DEFAULT_PRECISION = "f16x3"
-DEFAULT_HALF = "1"
 DEFAULT_HELPERS_MIN_ROWS = "65536"     # = GC_HELPERS_MIN_ROWS_DEFAULT (include/gcast.h); see StepEngine.helpers_min_rows
 
 # stage tags reported by gc_time_program / used by bench.py
@@ -89,10 +87,6 @@ class _Mlp:
       pack2 = lambda w, np_cols: _PW(up(packing.pack_weight_bf16(w, np_cols=np_cols, chained=True)
                                        .view(np.int16)))
       b1, b2 = packing.bf16_round(b1), packing.bf16_round(b2)
-    elif prec == nat.PREC_BF16_GEMM:
-      pack1 = lambda w: _PW(up(packing.pack_weight_bf16(w).view(np.int16)))
-      pack2 = lambda w, np_cols: _PW(up(packing.pack_weight_bf16(w, np_cols=np_cols, chained=True)
-                                       .view(np.int16)))
     else:
       pack1 = lambda w: _PW(up(packing.pack_weight(w)))
       pack2 = lambda w, np_cols: _PW(up(packing.pack_weight(w, np_cols=np_cols)))
@@ -177,12 +171,12 @@ class StepEngine:
       raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
     self.precision = precision
     self.prec = nat.PRECISIONS[precision]
-    # f16x3 only: `half` / GCAST_HALF selects the half-N formulation for EVERY launch (csrc/
-    # rowmlp_half.inc: <= 256 VGPRs and 66 KiB of LDS per workgroup, two workgroups per CU, so one
-    # tile's non-GEMM phases run under the other's MFMAs).  Same packed weights as the chunked kernels.
-    if half is None:
-      half = os.environ.get("GCAST_HALF", DEFAULT_HALF) == "1"
-    self.half = (bool(half) and self.prec == nat.PREC_F16X3) or self.prec == nat.PREC_BF16
+    # f16x3 and bf16 run the half-N formulation (csrc/rowmlp_half.inc, rowmlp_bf16.inc: <= 256 VGPRs and 75 KiB of
+    # LDS per workgroup, two workgroups per CU, so one tile's non-GEMM phases run under the other's MFMAs); f32 the
+    # chunked round-1 kernel.  `half=False` with f16x3 asked for the chunked f16x3 kernel of rounds 1-4: retired.
+    if half is False and self.prec == nat.PREC_F16X3:
+      raise ValueError("half=False: the chunked f16x3 kernels were retired in round 5 (f16x3 runs the half-N kernels)")
+    self.half = self.prec in (nat.PREC_F16X3, nat.PREC_BF16)
     self.scratch = None
     # f16x3 half-N kernels: the device word the launches fed by EXTERNAL rows set when a value exceeds the exact
     # range of the split halves (include/gcast.h: gc_rowmlp_desc.range_flag); read by check_range()

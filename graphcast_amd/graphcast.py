@@ -115,7 +115,7 @@ class GraphCast(predictor_base.Predictor):
     self._task_config = task_config
     self._device = device
     self._precision = precision       # None -> engine default / GCAST_PRECISION
-    self._half = half                 # f16x3 only: half-N kernels, two workgroups per CU (None -> GCAST_HALF / engine default)
+    self._half = half                 # (rounds 2-4: False selected the chunked f16x3 kernels, retired -- engine raises)
     self._spatial_features_kwargs = dict(
         add_node_positions=False, add_node_latitude=True, add_node_longitude=True,
         add_relative_positions=True, relative_longitude_local_coordinates=True,
@@ -145,7 +145,7 @@ class GraphCast(predictor_base.Predictor):
     self._engines = {}
 
   def set_precision(self, precision: Optional[str]) -> Optional[str]:
-    """Selects the GEMM arithmetic ("f16x3" | "f32" | "bf16gemm", None = default); returns the
+    """Selects the GEMM arithmetic ("f16x3" | "f32" | "bf16", None = default); returns the
     previous setting.  Engines are cached per precision (each holds its own packed weights)."""
     prev = self._precision
     if precision != prev:

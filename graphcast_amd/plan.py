@@ -44,11 +44,9 @@ class NativePlan:
     self.dev = torch.device(device)
     self.c_in, self.c_out = c_in, c_out
     self.n_grid = int(graphs["n_grid"])
-    if half is None:       # the same default as engine.StepEngine (bit-identical results, tests/test_plan_gpu.py)
-      import os
-      from graphcast_amd import engine
-      half = os.environ.get("GCAST_HALF", engine.DEFAULT_HALF) == "1"
-    self.half = (bool(half) and precision == "f16x3") or precision == "bf16"     # (the Bfloat16Cast tier exists in this formulation only)
+    if half is False and precision == "f16x3":
+      raise ValueError("half=False: the chunked f16x3 kernels were retired in round 5")
+    self.half = precision in ("f16x3", "bf16")       # the half-N formulation (f32: the chunked exact-fp32 kernel)
     keep = []
 
     def edge_set(g):

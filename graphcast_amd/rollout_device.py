@@ -56,6 +56,9 @@ def _coded_like(ds: xarray.Dataset, base: int, time_scale: int = 1000) -> xarray
 def _channel_codes(ds: xarray.Dataset):
   """[(name, time idx or -1, level idx or -1)] per stacked channel, in the stacking order."""
   names = sorted(ds.keys())
+  # (ONE grid point is enough to read the channel order off: at the full 0.25 deg grid the index-valued float64
+  #  twins of the inputs are 5 GB and building + stacking them cost 2.7 s per rollout, profiles/r05_s3_*)
+  ds = ds.isel({d: slice(0, 1) for d in ("lat", "lon") if d in ds.sizes})
   stacked = model_utils.dataset_to_stacked(_coded_like(ds, 0))
   codes = np.asarray(stacked.values).reshape(-1, stacked.shape[-1])[0]
   out = []

@@ -70,13 +70,11 @@ extern "C" {
  *                 v_mfma_f32_16x16x32_f16 accumulating in fp32 (dropped term
  *                 ~2^-22): fp32-grade results at 1/3 of the 2.5 PF f16 MFMA
  *                 peak.  |x| must stay below 1.3e5 (saturating split).
- *   GC_PREC_BF16_GEMM  a reduced-precision TIER: GEMM operands rounded to bfloat16 (nearest
- *                 even), one v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; everything
- *                 between the GEMMs stays fp32.  NOT within the fp32 tolerance of the path
- *                 (~3e-3 rel-RMSE) and NOT the numerics of the reference's Bfloat16Cast
- *                 (utils/casting.py:45-65 runs the activations in bfloat16 too -- not built);
- *                 weights packed as the hi-only image
- *                 [NP/16 n-blocks][64 lanes][8 bf16] per 32-row K chunk (NP * 64 bytes).
+ *   GC_PREC_BF16_IMAGE  (= 2) NOT a launch precision any more: rounds 1-4 ran a "bf16gemm" tier under this value
+ *                 (GEMM operands rounded to bfloat16, fp32 everywhere else -- numerics the reference does not have;
+ *                 retired in round 5).  The value still names its weight image -- bfloat16, hi-only,
+ *                 [NP/16 n-blocks][64 lanes][8 bf16] per 32-row K chunk (NP * 64 bytes) -- which GC_PREC_BF16
+ *                 uses, for gc_host_pack_weight / gc_host_packed_weight_bytes.
  *   GC_PREC_BF16  the TIER that follows the reference's casting.Bfloat16Cast run (utils/casting.py:31-65,
  *                 155-205; fp32 aggregation only where graphcast.py:215 asks for it is over-fulfilled:
  *                 every aggregation accumulates in fp32): ALL row tensors -- a0 / a1 (unless
@@ -86,13 +84,13 @@ extern "C" {
  *                 b2, LayerNorm, chain biases) stay fp32 [512] in natural order and should hold
  *                 bfloat16-representable values; `partial` rows are fp32 in pi order; a
  *                 GC_CHAIN_NARROW output is fp32, natural order, bfloat16-rounded values.  Weights: the
- *                 GC_PREC_BF16_GEMM image; every matrix whose K operand is a bfloat16 row tensor (or
+ *                 GC_PREC_BF16_IMAGE image; every matrix whose K operand is a bfloat16 row tensor (or
  *                 a launch's own rows) in the CHAINED K order, one fed by GC_ROWS_F32 rows in the
  *                 natural one; no weight scales.  GC_LAYOUT_HALF + GC_MODE_MLP_LN launches only; no
  *                 `scratch`.  Values are rounded to bfloat16 (nearest even) where the reference's
  *                 program materialises an array (csrc/rowmlp_bf16.inc); ~1e-2 rel-RMSE from the fp32
  *                 step -- the reference's own bf16 run is as far away. */
-enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_GEMM = 2, GC_PREC_BF16 = 3 };
+enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /* not a launch precision, see above */, GC_PREC_BF16 = 3 };
 
 /* gc_rowmlp_desc.flags */
 #define GC_ROWS_F32 1            /* GC_PREC_BF16: a0 / a1 are external fp32 rows in natural column order */

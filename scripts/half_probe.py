@@ -281,7 +281,8 @@ def main():
     with open(args.out, "w") as f:
       json.dump(out, f, indent=1)
     return
-  libs = [("chunked", load(nat.library_path()), nat.LAYOUT_CHUNKED), ("half", load(nat.library_path()), nat.LAYOUT_HALF)]
+  # (rounds 2-4 also timed the chunked f16x3 kernels of round 1 here: retired in round 5, GC_PREC_F16X3 == GC_LAYOUT_HALF)
+  libs = [("half", load(nat.library_path()), nat.LAYOUT_HALF)]
   for spec in filter(None, os.environ.get("HALF_BUILDS", "").split(";")):
     tag, _, defs = spec.partition(":")
     if defs.startswith("@"):          # a library compiled beforehand (travels with the snapshot): tag:@relative/path.so

@@ -45,5 +45,13 @@ case "$NAME" in
     GCAST_PRIO=0,0,0 timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_prio0.json" 2> "$OUT/bench_prio0.err"; echo "bench rc=$?"; show "$OUT/bench_prio0.json"
     timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8.json" 2>&1 | tail -5
     ;;
+  s4)
+    # Round-5 session 4: after the prune (chunked f16x3 kernels + the bf16gemm tier gone) -- smoke + the GPU tests that
+    # drive launches directly, then the bench line with rollout_api (channel tables from ONE grid point).
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -2 "$OUT/smoke.log"
+    timeout 1200 python -m pytest tests/test_rowmlp_gpu.py tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_bf16_tier_gpu.py tests/test_native_abi.py tests/test_deepgnn_gpu.py tests/test_conditioned_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log"
+    gate "$OUT/pytest.log" "prune"
+    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

@@ -27,15 +27,12 @@ def case():
   return dict(graphs=graphs, params=params, steps=steps, c_in=c_in, c_out=c_out)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x3h", "f32", "bf16gemm", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16"])
 @pytest.mark.parametrize("batch", [1, 2])
 def test_native_plan_equals_python_plan_bit_for_bit(case, precision, batch):
   # "bf16" (round 4): the Bfloat16Cast tier behind gc_plan_create / gc_step_forward -- C++ packers, the folded constants
   # rounded once to bfloat16 in pi order, bfloat16 workspace rows: the same bits as engine.StepEngine(precision="bf16")
-  # "f16x3h": f16x3 arithmetic, every launch in the half-N formulation (GC_LAYOUT_HALF)
-  half = precision == "f16x3h"
-  precision = "f16x3" if half else precision
-  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"], precision=precision, half=half)
+  kw = dict(num_steps=case["steps"], c_in=case["c_in"], c_out=case["c_out"], precision=precision)
   eng = engine.StepEngine(case["graphs"], case["params"], **kw)
   nat_plan = plan.NativePlan(case["graphs"], case["params"], **kw)
   rng = np.random.default_rng(batch)
@@ -48,7 +45,7 @@ def test_native_plan_equals_python_plan_bit_for_bit(case, precision, batch):
   again = nat_plan(x)                         # workspace reuse, determinism
   torch.cuda.synchronize()
   assert torch.equal(again, got)
-  if precision not in ("bf16gemm", "bf16") and batch == 1:
+  if precision != "bf16" and batch == 1:
     ref = ogc.forward(case["params"], case["graphs"], x.cpu().numpy(), steps=case["steps"], dtype=np.float64)
     err = float(np.linalg.norm(got.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref))
     print(f"native plan vs float64 oracle ({precision}): rel-RMSE {err:.2e}")
@@ -173,7 +170,7 @@ def test_plan_range_check_raises_on_out_of_range_inputs(case):
   p(torch.from_numpy(x).to("cuda:0"))              # the next step clears the word
   p.check_range()
   p.close()
-  q = plan.NativePlan(case["graphs"], case["params"], precision="f32", half=False, **kw)
+  q = plan.NativePlan(case["graphs"], case["params"], precision="f32", **kw)
   y = q(torch.from_numpy(big).to("cuda:0"))
   q.check_range()
   assert torch.isfinite(y).all()

@@ -15,10 +15,15 @@ def lib():
   return nat.lib()
 
 
+# gc_host_pack_weight's image ids: the launch precisions + the plain bfloat16 image the GC_PREC_BF16 tier packs its
+# parameters in (include/gcast.h: GC_PREC_BF16_IMAGE)
+_PACK_ID = {"f32": nat.PREC_F32, "f16x3": nat.PREC_F16X3, "bf16image": nat.PREC_BF16_IMAGE}
+
+
 @pytest.mark.parametrize("k,n,np_cols,chained", [(512, 512, 512, False), (474, 512, 512, False),
                                                  (512, 227, 256, True), (4, 512, 512, False),
                                                  (1024, 512, 512, False), (512, 512, 512, True)])
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16gemm"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16image"])
 def test_host_pack_weight_equals_numpy_packer(lib, prec, k, n, np_cols, chained):
   rng = np.random.default_rng(k + n)
   w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
@@ -32,11 +37,11 @@ def test_host_pack_weight_equals_numpy_packer(lib, prec, k, n, np_cols, chained)
   else:
     want, want_scale = packing.pack_weight_bf16(w, np_cols=np_cols, chained=chained), 1.0
   scale = ctypes.c_float(0)
-  size = lib.gc_host_pack_weight(nat.PRECISIONS[prec], int(chained), w.ctypes.data, k, n, np_cols, None,
+  size = lib.gc_host_pack_weight(_PACK_ID[prec], int(chained), w.ctypes.data, k, n, np_cols, None,
                                  ctypes.byref(scale))
   assert size == want.nbytes
   got = np.empty(size, dtype=np.uint8)
-  assert lib.gc_host_pack_weight(nat.PRECISIONS[prec], int(chained), w.ctypes.data, k, n, np_cols,
+  assert lib.gc_host_pack_weight(_PACK_ID[prec], int(chained), w.ctypes.data, k, n, np_cols,
                                  got.ctypes.data, ctypes.byref(scale)) == size
   assert scale.value == want_scale
   np.testing.assert_array_equal(got, np.ascontiguousarray(want).view(np.uint8).ravel())
@@ -152,7 +157,7 @@ def test_property_pack_edges_native_equals_numpy(n_recv, n_edges, seed, uniform)
 
 
 @settings(max_examples=25, deadline=None)
-@given(st.integers(1, 70), st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.sampled_from(["f32", "f16x3", "bf16gemm"]),
+@given(st.integers(1, 70), st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.sampled_from(["f32", "f16x3", "bf16image"]),
        st.booleans(), st.floats(1e-4, 30.0))
 def test_property_pack_weight_native_equals_numpy(k, n, seed, prec, chained, magnitude):
   rng = np.random.default_rng(seed)
@@ -169,7 +174,7 @@ def test_property_pack_weight_native_equals_numpy(k, n, seed, prec, chained, mag
     want, want_scale = packing.pack_weight_bf16(w, np_cols=np_cols, chained=chained), 1.0
   scale = ctypes.c_float(0)
   got = np.empty(want.nbytes, dtype=np.uint8)
-  assert lib.gc_host_pack_weight(nat.PRECISIONS[prec], int(chained), w.ctypes.data, k, n, np_cols,
+  assert lib.gc_host_pack_weight(_PACK_ID[prec], int(chained), w.ctypes.data, k, n, np_cols,
                                  got.ctypes.data, ctypes.byref(scale)) == want.nbytes
   assert scale.value == want_scale
   np.testing.assert_array_equal(got, np.ascontiguousarray(want).view(np.uint8).ravel())

@@ -192,35 +192,15 @@ def test_device_rollout_matches_dataset_rollout(setup):
   np.testing.assert_array_equal(got.coords["time"].values, template.coords["time"].values)
 
 
-def test_bf16_gemm_tier(setup):
-  """casting.Bf16GemmTier around GraphCast (bfloat16 GEMM operands, fp32 elsewhere -- NOT the
-  numerics of the reference's Bfloat16Cast, utils/casting.py:45-65): checked against the oracle
-  with the same GEMM-operand rounding; the distance to the fp32-grade result is reported (the tier
-  is outside the 1e-4 budget by design)."""
+def test_disabled_bfloat16_cast_is_the_wrapped_predictor(setup):
+  """casting.Bfloat16Cast(enabled=False) -- the reference's switch (utils/casting.py:40-47) -- passes the call through."""
   from graphcast_amd import casting
-  from oracle import gnn as ognn
-  model, oracle = setup
+  model, _ = setup
   inputs, template, forcings = synthetic.make_example(gc.TASK_13, LAT, LON, seed=21)
   full = model(inputs, template, forcings)
-  got = casting.Bf16GemmTier(model)(inputs, template, forcings)
-  assert model._precision is None                      # restored
-  with ognn.gemm_operands("bf16"):
-    want = oracle(casting.to_bfloat16_values(inputs), template, casting.to_bfloat16_values(forcings))
-  worst, dist = 0.0, 0.0
-  for k in template.keys():
-    w = casting.to_bfloat16_values(xarray.Dataset({k: want[k]}))[k].values
-    worst = max(worst, _rel(got[k].values, w))
-    dist = max(dist, _rel(got[k].values, full[k].values))
-  print(f"bf16gemm tier: worst per-variable rel diff vs bf16-operand oracle {worst:.2e}; vs the fp32-grade path {dist:.2e}")
-  # two bf16 pipelines differing in fp32 summation order decorrelate to bf16 resolution within a
-  # few layers, so both comparisons are at that resolution
-  assert worst < 2e-2
-  assert 1e-4 < dist < 5e-2
-  # disabled wrapper = the wrapped predictor
-  same = casting.Bf16GemmTier(model, enabled=False)(inputs, template, forcings)
-  np.testing.assert_array_equal(same["temperature"].values, full["temperature"].values)
   same = casting.Bfloat16Cast(model, enabled=False)(inputs, template, forcings)
   np.testing.assert_array_equal(same["temperature"].values, full["temperature"].values)
+  assert model._precision is None
 
 
 def test_bfloat16_cast_wrapper(setup):

@@ -25,15 +25,17 @@ REL_RMSE_TOL = {"f32": 2e-6, "f16x3": 3e-6, "bf16gemm": 5e-5}
 MAX_ABS_TOLS = {"f32": 2e-4, "f16x3": 2e-4, "bf16gemm": 2e-2}
 MAX_ABS_TOL = 2e-4
 _PREC = "f32"          # set per test by the autouse fixture below
-_HALF = False          # "f16x3h": every launch runs the half-N formulation, two workgroups per CU (GC_LAYOUT_HALF)
+_HALF = False          # f16x3: every launch runs the half-N formulation, two workgroups per CU (GC_LAYOUT_HALF)
 _SCRATCH = {}          # keeps the GC_LAYOUT_HALF scratch slots alive until the launch has run
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3h", "bf16gemm"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3"])
 def prec(request):
+  # (round 5 retired the chunked f16x3 kernels and the "bf16gemm" tier: "f16x3" = GC_LAYOUT_HALF, "f32" = the chunked
+  #  exact-fp32 kernel)
   global _PREC, _HALF
-  _HALF = request.param == "f16x3h"
-  _PREC = "f16x3" if _HALF else request.param
+  _PREC = request.param
+  _HALF = _PREC == "f16x3"
   return _PREC
 
 
@@ -622,3 +624,64 @@ def test_half_persistent_loop_revisits_scratch_slots(dev):
   h32 = out.cpu().numpy().astype(np.float64)
   want = ognn.swish(h32 @ ws.astype(np.float64)) @ wo.astype(np.float64) + bo[:n_out]
   assert_close(y.cpu().numpy(), want, "chained output MLP over many tiles per slot")
+
+
+def test_small_launches_give_the_same_bits_in_both_kernel_forms(dev):
+  """a node-side GC_LAYOUT_HALF launch of at most one tile per CU runs in the eight-wave helper form BY
+  DEFAULT (gcast.hip: the `small` rule) -- LINEAR, MLP_OUT and chained launches of callers who pass no flags (DeepGNN,
+  the conditioned encoder / decoder, every 1 deg launch).  Each of those shapes, with the four-wave form pinned
+  (GC_WG_NO_HELPERS), the eight-wave form asked for (GC_WG_HELPERS) and no flag at all: the same bits."""
+  _half_only()
+  rng = np.random.default_rng(77)
+  n_rows = 64 * 3 + 5
+
+  def run_all_forms(d, outs):
+    got = []
+    for flags in (nat.WG_NO_HELPERS, nat.WG_HELPERS, 0):
+      for o in outs:
+        o.fill_(float("nan"))
+      d.flags = flags
+      run(d)
+      got.append([o.clone() for o in outs])
+    for form in got[1:]:
+      for a, b in zip(got[0], form):
+        assert torch.equal(a, b)
+    assert all(torch.isfinite(o).all() for o in got[0])
+
+  # LINEAR
+  a = rng.standard_normal((n_rows, D)).astype(np.float32)
+  w = asymmetric_weight(rng, D, D)
+  ta, tw = up(a, dev), up(pw1(w), dev)
+  out = torch.zeros((n_rows, D), device=dev)
+  d = new_desc(nat.MODE_LINEAR, n_rows)
+  d.a0, d.lda0, d.k0, d.w1p = ta.data_ptr(), D, D, tw.data_ptr()
+  d.out, d.ldo = out.data_ptr(), D
+  run_all_forms(d, [out])
+  # MLP_OUT
+  n2 = 227
+  w1, b1 = asymmetric_weight(rng, D, D), (0.3 * rng.standard_normal(D)).astype(np.float32)
+  w2, b2 = asymmetric_weight(rng, D, n2), (0.3 * rng.standard_normal(n2)).astype(np.float32)
+  t = [up(pw1(w1), dev), up(b1, dev), up(pw2(w2, np_cols=256), dev), up(packing.pad_vector(b2, 256), dev)]
+  y = torch.zeros((n_rows, n2), device=dev)
+  d = new_desc(nat.MODE_MLP_OUT, n_rows)
+  d.a0, d.lda0, d.k0, d.w1p, d.b1 = ta.data_ptr(), D, D, t[0].data_ptr(), t[1].data_ptr()
+  d.w2p, d.b2, d.n2 = t[2].data_ptr(), t[3].data_ptr(), n2
+  d.out, d.ldo = y.data_ptr(), n2
+  run_all_forms(d, [y])
+  # MLP_LN + residual + two chained row stages
+  p = _mlp_ln_case(rng, n_rows, D, D)
+  res = rng.standard_normal((n_rows, D)).astype(np.float32)
+  ws, wr = asymmetric_weight(rng, D, D), asymmetric_weight(rng, D, D)
+  tt = {k: up(v, dev) for k, v in dict(a0=p["a0"], a1=p["a1"], b1=p["b1"], b2=p["b2"], scale=p["scale"],
+                                        offset=p["offset"], res=res).items()}
+  tw1, tw2, tws, twr = up(pw1(p["w1"]), dev), up(pw2(p["w2"]), dev), up(pw2(ws), dev), up(pw2(wr), dev)
+  o, o_s, o_r = (torch.zeros((n_rows, D), device=dev) for _ in range(3))
+  d = new_desc(nat.MODE_MLP_LN, n_rows)
+  d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = tt["a0"].data_ptr(), D, D, tt["a1"].data_ptr(), D, D
+  d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), tt["b1"].data_ptr(), tw2.data_ptr(), tt["b2"].data_ptr(), D
+  d.ln_scale, d.ln_offset = tt["scale"].data_ptr(), tt["offset"].data_ptr()
+  d.res, d.ldres, d.out, d.ldo = tt["res"].data_ptr(), D, o.data_ptr(), D
+  d.n_chain = 2
+  _chain_stage(d, 0, tws, nat.CHAIN_ROWS, out=o_s, ldo=D)
+  _chain_stage(d, 1, twr, nat.CHAIN_ROWS, out=o_r, ldo=D)
+  run_all_forms(d, [o, o_s, o_r])
