@@ -1250,7 +1250,7 @@ int gc_time_program(const gc_op* ops, int n_ops, int iters, float* h_ms, void* s
 
 size_t gc_abi_sizeof(int what) {
   return what == 0 ? sizeof(gc_rowmlp_desc) : what == 1 ? sizeof(gc_op)
-         : what == 2 ? sizeof(gc_advance_desc) : 0;
+         : what == 2 ? sizeof(gc_advance_desc) : what == 3 ? sizeof(gc_model_desc) : 0;
 }
 
 const char* gc_last_error(void) { return g_err; }

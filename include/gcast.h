@@ -396,6 +396,13 @@ typedef struct gc_model_desc {
                                 GC_LAYOUT_HALF (GC_PREC_F16X3: the workspace then includes the launches' scratch
                                 rows; GC_PREC_BF16, the Bfloat16Cast tier, exists in this formulation only:
                                 bfloat16 workspace rows, constants folded by the fp32-grade kernels at creation) */
+  /* Spatially partitioned graphs (round 5; one rank's LOCAL graphs, graphcast_amd/partition.py): the node tables that
+   * edges GATHER from carry a halo suffix of remote sender rows behind the owned rows -- sender indices >= n_grid /
+   * n_mesh address it; the launches run over the owned prefix, the caller's halo exchange fills the suffix at the
+   * program's exchange points (gc_plan_program: right in front of every edge update).  Rows of the grid-node table
+   * of the encoder's senders, of the mesh-node tables of the processor's and of the decoder's senders; 0 = no halo
+   * (= n_grid / n_mesh).  */
+  int n_grid_senders, n_mesh_senders, n_mesh_senders_dec;
 } gc_model_desc;
 
 typedef struct gc_tensor_desc {
@@ -415,6 +422,29 @@ int gc_step_forward(const gc_plan* plan, const float* x, float* y, int batch, vo
  * the word of the LAST gc_step_forward on this workspace and returns 0 or GC_ERANGE (message in gc_last_error):
  * call it wherever the host synchronises anyway, before trusting y.  Other precisions: always 0. */
 int gc_plan_check_range(const gc_plan* plan, void* workspace, void* stream);
+
+/* The plan's launch program, handed out instead of enqueued (round 5): the ops gc_step_forward(plan, x, y, batch,
+ * workspace) would run, in order, each tagged with its stage (enum gc_stage_tag).  THE one program builder: the Python
+ * engine (graphcast_amd/engine.py: stage-wise verification hooks, per-launch timing, the halo-exchange cut points of
+ * the spatially partitioned step) drives this array through gc_run_program / gc_time_program instead of recording
+ * its own.  `ops` has room for `capacity` entries; *n_ops receives the count (GC_EINVAL if it does not fit).  Unlike
+ * gc_step_forward nothing is cleared: the caller zeroes the workspace's "tile_queue" (2 ints) before running a
+ * program or a prefix of it, and owns the "range_flag" word (gc_plan_tensor).  Exchange points of a partitioned
+ * model: immediately before each GC_OP_ROWMLP op tagged GC_TAG_ENC_EDGE / GC_TAG_PROC_EDGE / GC_TAG_DEC_EDGE the
+ * halo suffix of "pre_grid" / "pre_s_mesh" / "pre_s_mesh" must have been filled. */
+enum gc_stage_tag { GC_TAG_PREP = 0, GC_TAG_ENC_EMBED_GRID = 1, GC_TAG_ENC_PRE = 2, GC_TAG_ENC_EDGE = 3,
+                    GC_TAG_ENC_NODE_MESH = 4, GC_TAG_ENC_NODE_GRID = 5, GC_TAG_PROC_PRE = 6, GC_TAG_PROC_EDGE = 7,
+                    GC_TAG_PROC_NODE = 8, GC_TAG_DEC_PRE = 9, GC_TAG_DEC_EDGE = 10, GC_TAG_DEC_NODE = 11,
+                    GC_TAG_DEC_OUT = 12, GC_TAG_FIXUP = 13 };
+int gc_plan_program(const gc_plan* plan, const float* x, float* y, int batch, void* workspace,
+                    size_t workspace_bytes, gc_op* ops, int capacity, int* n_ops);
+/* A named tensor of the plan / its workspace: device pointer, rows, columns, bytes per element (4, or 2 for the
+ * bfloat16 row tensors of a GC_PREC_BF16 plan).  Workspace tensors (need `workspace`): "xin", "h_grid", "pre_grid",
+ * "h_grid2", "agg_grid", "h_mesh", "agg_mesh", "pre_s_mesh", "pre_r_mesh", "e_mesh_lat", "range_flag" (1 int),
+ * "tile_queue" (2 ints); constants folded at creation: "h_mesh0", "d_g2m", "d_enc_mesh", "e_mesh0", "d_mesh0",
+ * "d_m2g".  Returns GC_EINVAL for an unknown name (or a tensor this plan does not have). */
+int gc_plan_tensor(const gc_plan* plan, void* workspace, const char* name, void** ptr, long long* rows, int* cols,
+                   int* elem_bytes);
 void gc_plan_destroy(gc_plan* plan);
 
 /* Host-side packers the plan uses, exported so that a binding can check them bit for bit
@@ -432,7 +462,7 @@ int gc_host_pack_edges(int n_edges, const int* h_senders, const int* h_receivers
                        long long* h_perm, int* h_snd, int* h_rcv, int* h_flags,
                        int* h_fix, int* n_fix, int* h_empty, int* n_empty);
 
-/* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for 1, sizeof(gc_advance_desc) for 2, 0 otherwise:
+/* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for 1, sizeof(gc_advance_desc) for 2, sizeof(gc_model_desc) for 3, 0 otherwise:
  * lets a foreign-language binding verify its struct layout at load time. */
 size_t gc_abi_sizeof(int what);
 
