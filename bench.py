@@ -658,8 +658,7 @@ def partition_main(args, rank, world, device, distributed):
         "config": {"workload": f"GraphCast {args.config}: ONE encode-process-decode 6-h step partitioned over {world} GPU(s)",
                    "parallelism": f"octant partition x{world} (partition.plan: hemispheres / quadrants / octants), receiver-owned "
                                   f"edges, 18 halo exchanges per step = one RCCL all_to_all_single each",
-                   "rank0_rows": {"grid": mine.n_grid_owned, "mesh": mine.n_mesh_owned, "halo": halo},
-                   "overlap": os.environ.get("GCAST_OVERLAP", "0") == "1"},
+                   "rank0_rows": {"grid": mine.n_grid_owned, "mesh": mine.n_mesh_owned, "halo": halo}},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "precision": precision, "output_finite": finite,

@@ -93,7 +93,9 @@ class ModelDesc(ctypes.Structure):
   _fields_ = [("n_grid", ctypes.c_int), ("n_mesh", ctypes.c_int), ("c_in", ctypes.c_int),
               ("c_out", ctypes.c_int), ("n_struct", ctypes.c_int), ("num_steps", ctypes.c_int),
               ("prec", ctypes.c_int), ("h_grid_node_feat", _fp), ("h_mesh_node_feat", _fp),
-              ("g2m", EdgeSet), ("mesh", EdgeSet), ("m2g", EdgeSet), ("layout", ctypes.c_int)]
+              ("g2m", EdgeSet), ("mesh", EdgeSet), ("m2g", EdgeSet), ("layout", ctypes.c_int),
+              # spatially partitioned graphs: rows of the sender tables incl. their halo suffix (0 = none)
+              ("n_grid_senders", ctypes.c_int), ("n_mesh_senders", ctypes.c_int), ("n_mesh_senders_dec", ctypes.c_int)]
 
 
 class TensorDesc(ctypes.Structure):
@@ -115,6 +117,7 @@ class AdvanceDesc(ctypes.Structure):
 
 
 EXPORTS = ("gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_plan_check_range", "gc_plan_destroy",
+           "gc_plan_program", "gc_plan_tensor",
            "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_add_rows", "gc_prep_grid_input", "gc_prep_grid_tail",
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
@@ -292,6 +295,12 @@ def lib():
     l.gc_plan_check_range.restype = ctypes.c_int
     l.gc_plan_destroy.argtypes = [ctypes.c_void_p]
     l.gc_plan_destroy.restype = None
+    l.gc_plan_program.argtypes = [ctypes.c_void_p, _fp, _fp, ctypes.c_int, _fp, ctypes.c_size_t, ctypes.POINTER(Op),
+                                  ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    l.gc_plan_program.restype = ctypes.c_int
+    l.gc_plan_tensor.argtypes = [ctypes.c_void_p, _fp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p),
+                                 ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    l.gc_plan_tensor.restype = ctypes.c_int
     l.gc_host_pack_weight.argtypes = [ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _fp, ctypes.POINTER(ctypes.c_float)]
     l.gc_host_pack_weight.restype = ctypes.c_size_t
@@ -302,7 +311,7 @@ def lib():
     l.gc_abi_sizeof.argtypes = [ctypes.c_int]
     l.gc_abi_sizeof.restype = ctypes.c_size_t
     if (l.gc_abi_sizeof(0) != ctypes.sizeof(RowMlpDesc) or l.gc_abi_sizeof(1) != ctypes.sizeof(Op)
-        or l.gc_abi_sizeof(2) != ctypes.sizeof(AdvanceDesc)):
+        or l.gc_abi_sizeof(2) != ctypes.sizeof(AdvanceDesc) or l.gc_abi_sizeof(3) != ctypes.sizeof(ModelDesc)):
       raise RuntimeError("ctypes struct layout does not match include/gcast.h "
                          f"({l.gc_abi_sizeof(0)}/{ctypes.sizeof(RowMlpDesc)}, "
                          f"{l.gc_abi_sizeof(1)}/{ctypes.sizeof(Op)}); rebuild the library")

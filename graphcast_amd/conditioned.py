@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from graphcast_amd import _native as nat
-from graphcast_amd import engine
+from graphcast_amd import launch
 from graphcast_amd import packing
 
 D = packing.LATENT
@@ -46,7 +46,7 @@ class _Cond:
     self.k = kc
 
 
-class ConditionedEncoderDecoder(engine.StepEngine):
+class ConditionedEncoderDecoder(launch.LaunchBase):
   """grid2mesh encoder + mesh2grid decoder with ``global_norm_conditioning``.
 
   graphs: ``n_grid``, ``n_mesh``, ``g2m`` / ``m2g`` = dict(senders, receivers, feat [E, <=32]).
@@ -60,12 +60,12 @@ class ConditionedEncoderDecoder(engine.StepEngine):
                c_out: int, device="cuda:0", precision: Optional[str] = None):
     self.dev = torch.device(device)
     self.lib = nat.lib()
-    precision = precision or engine.DEFAULT_PRECISION
+    precision = precision or launch.DEFAULT_PRECISION
     self.precision, self.prec = precision, nat.PRECISIONS[precision]
     import os
     self.half = self.prec == nat.PREC_F16X3
     self.scratch = None
-    # latents come from the caller: every launch that reads rows carries the f16x3 range flag (engine.StepEngine.check_range)
+    # latents come from the caller: every launch that reads rows carries the f16x3 range flag (launch.LaunchBase.check_range)
     self.check_all_rows = True
     self.range_flag = (torch.zeros((1,), dtype=torch.int32, device=self.dev)
                        if self.half and self.prec == nat.PREC_F16X3 else None)
@@ -76,7 +76,7 @@ class ConditionedEncoderDecoder(engine.StepEngine):
       raise NotImplementedError("decoder width above 240 needs a wider output tile")
     self._keep = []
     dev = self.dev
-    M = lambda stem, **kw: engine._Mlp(params, stem, dev, prec=self.prec, **kw)
+    M = lambda stem, **kw: launch._Mlp(params, stem, dev, prec=self.prec, **kw)
     esr = ("e", "s", "r")
     self.m_enc_grid = M(_G + "encoder_nodes_grid_nodes")
     self.m_enc_mesh = M(_G + "encoder_nodes_mesh_nodes")
@@ -99,7 +99,7 @@ class ConditionedEncoderDecoder(engine.StepEngine):
       # the same packing _Mlp applies to a first-layer matrix of this precision
       holder = {"x_mlp/~/linear_0": {"w": w, "b": np.zeros(D, np.float32)},
                 "x_mlp/~/linear_1": {"w": np.zeros((D, D), np.float32), "b": np.zeros(D, np.float32)}}
-      return engine._Mlp(holder, "x", dev, prec=self.prec).w1
+      return launch._Mlp(holder, "x", dev, prec=self.prec).w1
 
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     cond_stems = dict(
@@ -112,9 +112,9 @@ class ConditionedEncoderDecoder(engine.StepEngine):
     self._keep += [self.m_enc_grid, self.m_enc_mesh, self.m_enc_e_g2m, self.m_g2m_edge, self.m_g2m_mesh,
                    self.m_g2m_grid, self.m_enc_e_m2g, self.m_m2g_edge, self.m_m2g_grid, self.m_out, self.cond]
 
-    self.e_g2m = engine._Edges(packing.pack_edges(graphs["g2m"]["senders"], graphs["g2m"]["receivers"],
+    self.e_g2m = launch._Edges(packing.pack_edges(graphs["g2m"]["senders"], graphs["g2m"]["receivers"],
                                                   self.n_mesh), dev)
-    self.e_m2g = engine._Edges(packing.pack_edges(graphs["m2g"]["senders"], graphs["m2g"]["receivers"],
+    self.e_m2g = launch._Edges(packing.pack_edges(graphs["m2g"]["senders"], graphs["m2g"]["receivers"],
                                                   self.n_grid), dev)
 
     def edge_feat_rows(edges, feat):

@@ -36,7 +36,7 @@ import numpy as np
 import torch
 
 from graphcast_amd import _native as nat
-from graphcast_amd import engine
+from graphcast_amd import launch
 from graphcast_amd import packing
 from graphcast_amd import typed_graph
 
@@ -56,7 +56,7 @@ def _check_dense(kw, what):
                               "conditioning are not built")
 
 
-class DeepGNN(engine.StepEngine):
+class DeepGNN(launch.LaunchBase):
   """See the module docstring."""
 
   def __init__(self, *, dense_kwargs: Mapping[str, Any], num_message_passing_steps: int,
@@ -80,13 +80,13 @@ class DeepGNN(engine.StepEngine):
     # ---- the parts of StepEngine this class uses (it does not run the GraphCast step program)
     self.dev = torch.device(device)
     self.lib = nat.lib()
-    precision = precision or engine.DEFAULT_PRECISION
+    precision = precision or launch.DEFAULT_PRECISION
     if precision not in ("f16x3", "f32"):
       raise NotImplementedError("DeepGNN on MI355X runs in the fp32-grade precisions (f16x3 | f32)")
     self.precision, self.prec = precision, nat.PRECISIONS[precision]
     self.half = self.prec == nat.PREC_F16X3
     self.onepass, self.scratch, self._keep = False, None, []
-    # latents come from the caller: every launch that reads rows carries the f16x3 range flag (engine.StepEngine.check_range)
+    # latents come from the caller: every launch that reads rows carries the f16x3 range flag (launch.LaunchBase.check_range)
     self.check_all_rows = True
     self.range_flag = (torch.zeros((1,), dtype=torch.int32, device=self.dev)
                        if self.half and self.prec == nat.PREC_F16X3 else None)
@@ -95,7 +95,7 @@ class DeepGNN(engine.StepEngine):
 
   # ---------------------------------------------------------------- parameters
   def _legacy_view(self, i, edge_name, node_names):
-    """The step's modules under the names engine._Mlp reads (``<stem>_mlp/~/linear_k``, ``<stem>_layer_norm``);
+    """The step's modules under the names launch._Mlp reads (``<stem>_mlp/~/linear_k``, ``<stem>_layer_norm``);
     the pre-gather form's three matrices stacked back into [W_e; W_s; W_r]."""
     p, n = self._params, self._name
     view = {}
@@ -131,9 +131,9 @@ class DeepGNN(engine.StepEngine):
     for i in range(self._steps):
       view = self._legacy_view(i, edge_name, nodes)
       out.append(dict(
-          edge=engine._Mlp(view, "E", self.dev, split=("e", "s", "r"), prec=self.prec),
-          recv=engine._Mlp(view, "N0", self.dev, prec=self.prec),
-          send=engine._Mlp(view, "N1", self.dev, prec=self.prec) if len(nodes) > 1 else None))
+          edge=launch._Mlp(view, "E", self.dev, split=("e", "s", "r"), prec=self.prec),
+          recv=launch._Mlp(view, "N0", self.dev, prec=self.prec),
+          send=launch._Mlp(view, "N1", self.dev, prec=self.prec) if len(nodes) > 1 else None))
     self._keep.append(out)
     self._mlps = (key, out)          # (a graph with other set names reads other parameter modules: rebuilt)
     return out
@@ -146,7 +146,7 @@ class DeepGNN(engine.StepEngine):
         raise NotImplementedError("DeepGNN on MI355X: padding edges (receiver index outside the node set) are not built")
       if len(s) and (s.min() < 0 or s.max() >= n_send):
         raise ValueError(f"DeepGNN: sender index outside the sender node set (0 <= s < {n_send})")
-      e = engine._Edges(packing.pack_edges(s, r, n_recv), self.dev)
+      e = launch._Edges(packing.pack_edges(s, r, n_recv), self.dev)
       ok = e.pk.perm >= 0
       e.src = torch.from_numpy(np.where(ok, e.pk.perm, 0).astype(np.int64)).to(self.dev)       # packed row -> edge
       e.ok = torch.from_numpy(ok).to(self.dev)

@@ -255,10 +255,11 @@ class EmulatedPartitionedStep:
     self.n_grid = int(graphs["n_grid"])
     self.c_out = c_out
     self.exchanges_per_call = 0
-    # edge updates split into sender-local and halo-sender launches (engine.StepEngine.halo): the exchange runs
-    # on a second stream under the first; GCAST_OVERLAP=0: one launch behind a blocking exchange
-    self.overlap = any(h is not None for e in self.engines for h in e.halo.values())
-    self._comm = None
+    # (rounds 3-4 could split every edge update into sender-local and halo-sender launches and run the exchange on a
+    #  second stream under the first -- GCAST_OVERLAP=1.  Retired in round 5 on the measurements: the 18 extra small
+    #  launches + joins cost 1.6 ms per rank at 8-way (profiles/r03_s9_*) against 0.47 ms for ALL 18 exchanges of a
+    #  step on the device (bench.py --mode partition: roofline.exchange, profiles/r05_s1_*) -- there is less to hide
+    #  than the hiding costs.  Every edge update is one launch behind a blocking exchange.)
 
   def forward(self, x):
     import torch
@@ -269,24 +270,13 @@ class EmulatedPartitionedStep:
     assert all([a for _, a in segs] == [a for _, a in bound[0][1]] for _, segs in bound), \
         "the ranks' segment / action lists differ"
     self.exchanges_per_call = 0
-    compute = torch.cuda.current_stream(x.device)
-    if self.overlap and self._comm is None:
-      self._comm = torch.cuda.Stream(device=x.device)
     for k in range(n_seg):
       for _, segs in bound:
         segs[k][0]()
       for kind, name in bound[0][1][k][1]:
         if kind == "start":
-          tables = [e.halo_table(name) for e in self.engines]
           self.exchanges_per_call += 1
-          if self.overlap:                 # the copies run on a second stream, under the sender-local edge launches
-            self._comm.wait_stream(compute)
-            with torch.cuda.stream(self._comm):
-              self.exchangers[name].exchange(tables)
-          else:
-            self.exchangers[name].exchange(tables)
-        elif self.overlap:                 # "wait": the halo-sender launches gather from the suffix
-          compute.wait_stream(self._comm)
+          self.exchangers[name].exchange([e.halo_table(name) for e in self.engines])
     y = torch.empty((self.n_grid, x.shape[1], self.c_out), dtype=torch.float32, device=x.device)
     for r, (yl, _) in zip(self.ranks, bound):
       y[torch.as_tensor(r.grid_owned, device=x.device)] = yl
@@ -307,31 +297,16 @@ class DistributedPartitionedStep:
                                     c_out=c_out, device=device, precision=precision)
     self.exchangers = {name: DistExchanger(pl, n_owned, device, group)
                        for name, (pl, n_owned) in tables_of(rank_graphs).items()}
-    self._comm = None
 
   def forward(self, x_local, y_local=None):
     """x_local = rows ``rank_graphs.grid_owned`` of the global [N_grid, B, C_in] input."""
     import torch
     y, segs = self.engine.segments(x_local, y_local)
-    overlap = any(h is not None for h in self.engine.halo.values())
-    dev = self.engine.dev
-    compute = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-    if overlap and self._comm is None and compute is not None:
-      self._comm = torch.cuda.Stream(device=dev)
     for run, actions in segs:
       run()
       for kind, name in actions:
-        if kind == "start":
-          table = self.engine.halo_table(name)
-          if overlap and self._comm is not None:
-            # ONE all_to_all_single on the communication stream, under the sender-local edge launch
-            self._comm.wait_stream(compute)
-            with torch.cuda.stream(self._comm):
-              self.exchangers[name].exchange(table)
-          else:
-            self.exchangers[name].exchange(table)
-        elif overlap and self._comm is not None:
-          compute.wait_stream(self._comm)
+        if kind == "start":                  # ONE all_to_all_single, in front of the edge update that gathers from the suffix
+          self.exchangers[name].exchange(self.engine.halo_table(name))
     return y
 
   __call__ = forward

@@ -1,38 +1,16 @@
-"""`NativePlan`: the step driven through the C-ABI's plan API (include/gcast.h:
-gc_plan_create / gc_step_forward) instead of the Python plan builder of engine.py.
-
-Same launches, same packed images -- the C++ packers in csrc/gcast_plan.inc mirror packing.py and
-StepEngine bit for bit (tests/test_plan_gpu.py) -- so this is what a C / C++ host of the library
-gets.  The Python side only flattens the reference-layout arrays into the C descriptors.
+"""`NativePlan`: the step driven through the C-ABI's plan API exactly as a C / C++ host drives it (include/gcast.h:
+gc_plan_create / gc_plan_workspace_bytes / gc_step_forward / gc_plan_check_range) -- two calls per step, an opaque
+workspace.  ``engine.StepEngine`` sits on the same plan and the same launch program (gc_plan_program), with the
+Python host's verification and partitioning hooks around it; the Python side here only flattens the reference-layout
+arrays into the C descriptors.
 """
 import ctypes
 from typing import Mapping, Optional
 
-import numpy as np
 import torch
 
 from graphcast_amd import _native as nat
-
-
-def _f32(a):
-  return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
-
-
-def _i32(a):
-  return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
-
-
-def tensor_descs(params: Mapping[str, Mapping[str, np.ndarray]]):
-  """haiku tree {"module": {"w": ...}} -> (TensorDesc array, keep-alive list), names "module/leaf"."""
-  keep, descs = [], []
-  for module, leaves in params.items():
-    for leaf, value in leaves.items():
-      a = _f32(value)
-      a2 = a.reshape(1, -1) if a.ndim == 1 else a
-      name = f"{module}/{leaf}".encode()
-      keep += [a2, name]
-      descs.append(nat.TensorDesc(name, a2.ctypes.data, a2.shape[0], a2.shape[1]))
-  return (nat.TensorDesc * len(descs))(*descs), keep
+from graphcast_amd.engine import create_plan, tensor_descs      # noqa: F401  (one flattening of the reference-layout arrays)
 
 
 class NativePlan:
@@ -47,25 +25,8 @@ class NativePlan:
     if half is False and precision == "f16x3":
       raise ValueError("half=False: the chunked f16x3 kernels were retired in round 5")
     self.half = precision in ("f16x3", "bf16")       # the half-N formulation (f32: the chunked exact-fp32 kernel)
-    keep = []
-
-    def edge_set(g):
-      s, r, f = _i32(g["senders"]), _i32(g["receivers"]), _f32(g["feat"])
-      keep.extend([s, r, f])
-      return nat.EdgeSet(len(s), s.ctypes.data, r.ctypes.data, f.ctypes.data, f.shape[1])
-
-    gnf, mnf = _f32(graphs["grid_node_feat"]), _f32(graphs["mesh_node_feat"])
-    keep += [gnf, mnf]
-    model = nat.ModelDesc(self.n_grid, int(graphs["n_mesh"]), c_in, c_out, gnf.shape[1], num_steps,
-                          nat.PRECISIONS[precision], gnf.ctypes.data, mnf.ctypes.data,
-                          edge_set(graphs["g2m"]), edge_set(graphs["mesh"]), edge_set(graphs["m2g"]),
-                          nat.LAYOUT_HALF if self.half else nat.LAYOUT_CHUNKED)
-    tensors, keep_t = tensor_descs(params)
-    handle = ctypes.c_void_p()
-    with torch.cuda.device(self.dev):
-      stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-      nat.check(self.lib.gc_plan_create(ctypes.byref(model), tensors, len(tensors), stream,
-                                        ctypes.byref(handle)), "gc_plan_create")
+    handle = create_plan(self.lib, graphs, params, num_steps=num_steps, c_in=c_in, c_out=c_out, precision=precision,
+                         device=self.dev)
     self._plan = handle
     self._ws: Optional[torch.Tensor] = None
 

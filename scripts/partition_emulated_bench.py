@@ -62,8 +62,7 @@ def main():
   ms_part = timed(lambda: step(x))
   ranks = step.ranks
   rows = lambda f: [int(f(r)) for r in ranks]
-  # the 18 exchanges alone, back to back (what a blocking exchange adds to the step; with split edge updates --
-  # step.overlap -- the copies run on a second stream under the sender-local launches instead)
+  # the 18 exchanges alone, back to back (what the blocking exchanges add to the step)
   tables = {n: [e.halo_table(n) for e in step.engines] for n in ("g2m", "mesh", "m2g")}
   def exchanges_only():
     step.exchangers["g2m"].exchange(tables["g2m"])
@@ -71,15 +70,12 @@ def main():
       step.exchangers["mesh"].exchange(tables["mesh"])
     step.exchangers["m2g"].exchange(tables["m2g"])
   ms_exchange = timed(exchanges_only)
-  halo_edges = {k: [int(e.halo[k].e.pk.n_rows) if e.halo[k] is not None else 0 for e in step.engines] for k in ("g2m", "mesh", "m2g")}
   out = {
       "config": f"GraphCast {args.config}, {args.parts} parts ({'octants' if args.parts == 8 else 'hemispheres / quadrants' if args.parts in (2, 4) else 'longitude bands'}), receiver-owned edges",
       "rel_diff_vs_unpartitioned": rel, "exchanges_per_step": step.exchanges_per_call,
       "ms_unpartitioned_step": ms_full, "ms_sum_of_all_ranks_emulated_on_one_gpu": ms_part,
       "ms_per_rank_if_perfectly_parallel": ms_part / args.parts,
-      "edge_updates_split_for_overlap": bool(step.overlap),
       "ms_all_exchanges_alone_all_ranks": ms_exchange,
-      "halo_sender_edge_rows_per_rank": halo_edges,
       "grid_rows_per_rank": rows(lambda r: r.n_grid_owned), "mesh_rows_per_rank": rows(lambda r: r.n_mesh_owned),
       "edges_per_rank": {k: rows(lambda r, k=k: len(r.graphs[k]["senders"])) for k in ("g2m", "mesh", "m2g")},
       "halo_rows_per_rank": {"g2m_grid_rows": rows(lambda r: len(r.halo_g2m.halo_global)),

@@ -53,5 +53,16 @@ case "$NAME" in
     gate "$OUT/pytest.log" "prune"
     timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
     ;;
+  s5)
+    # Round-5 session 5: ONE program builder -- engine.StepEngine on gc_plan_program / gc_plan_tensor, partitioned graphs
+    # through gc_model_desc's halo-table sizes, the Python recorder gone: smoke, the WHOLE GPU suite (without the 0.25 deg
+    # 40-step fixture test while that fixture is being regenerated), bench + partition-mode bench + the emulated 8-way.
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -2 "$OUT/smoke.log"
+    timeout 1500 python -m pytest tests -m gpu -q --timeout=900 --deselect tests/test_rollout40_fullsize_gpu.py > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -6 "$OUT/pytest.log" | cut -c1-400
+    grep -E "FULLSIZE_PARITY|ROLLOUT" "$OUT/pytest.log" | cut -c1-600
+    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
+    timeout 600 python bench.py --mode partition --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_partition_n1.json" 2> "$OUT/bench_partition.err"; echo "partition rc=$?"; show "$OUT/bench_partition_n1.json"
+    timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8.json" 2>&1 | tail -3 | cut -c1-600
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

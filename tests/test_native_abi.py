@@ -43,7 +43,8 @@ def test_struct_layout_matches_header(built):
   assert lib.gc_abi_sizeof(0) == ctypes.sizeof(nat.RowMlpDesc)
   assert lib.gc_abi_sizeof(1) == ctypes.sizeof(nat.Op)
   assert lib.gc_abi_sizeof(2) == ctypes.sizeof(nat.AdvanceDesc)
-  assert lib.gc_abi_sizeof(3) == 0
+  assert lib.gc_abi_sizeof(3) == ctypes.sizeof(nat.ModelDesc)      # (round 5: + the halo-table sizes)
+  assert lib.gc_abi_sizeof(4) == 0
 
 
 def test_argument_validation_needs_no_gpu(built):

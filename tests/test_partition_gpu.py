@@ -35,12 +35,10 @@ def setup():
               lat=lat, lon=lon, mesh_size=mesh_size)
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("n_parts", [2, 3, 8])
-def test_partitioned_step_equals_full_step(setup, n_parts, overlap, monkeypatch):
-  # overlap "1": every edge update split into its sender-local edges (the exchange runs on a second stream under
-  # that launch) and its halo-sender edges (launched behind the exchange, aggregate rows joined by gc_add_rows)
-  monkeypatch.setenv("GCAST_OVERLAP", overlap)
+def test_partitioned_step_equals_full_step(setup, n_parts):
+  # (round 5: each rank's engine is a C++ plan of its LOCAL graphs -- sender tables with a halo suffix,
+  #  gc_model_desc.n_*_senders -- and the exchange points are read off the plan's program)
   m = setup["model"]
   step = partition.EmulatedPartitionedStep(
       m.graph_arrays(), setup["params"], m._grid_nodes_lon, m._mesh_nodes_lon, n_parts,
@@ -49,7 +47,6 @@ def test_partitioned_step_equals_full_step(setup, n_parts, overlap, monkeypatch)
   y = step(setup["x"])
   torch.cuda.synchronize()
   assert step.exchanges_per_call == 2 * (2 + setup["steps"])        # batch 2 x (enc + steps + dec)
-  assert step.overlap == (overlap == "1")
   diff = (y - setup["y"]).double()
   rel = float(torch.linalg.vector_norm(diff) / torch.linalg.vector_norm(setup["y"].double()))
   print(f"{n_parts} parts: rel diff vs unpartitioned {rel:.2e}, "
@@ -66,7 +63,6 @@ def test_partitioned_step_in_the_bfloat16_tier(setup, n_parts, monkeypatch):
   the order of fp32 partial sums in front of ONE bfloat16 rounding: the two bf16 runs decorrelate at bfloat16
   resolution, and must sit at the same distance from the fp32-grade step."""
   from graphcast_amd import engine
-  monkeypatch.setenv("GCAST_OVERLAP", "0")
   m = setup["model"]
   full = engine.StepEngine(m.graph_arrays(), setup["params"], num_steps=setup["steps"], c_in=setup["c_in"],
                            c_out=setup["c_out"], device="cuda:0", precision="bf16")
