@@ -64,5 +64,22 @@ case "$NAME" in
     timeout 600 python bench.py --mode partition --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_partition_n1.json" 2> "$OUT/bench_partition.err"; echo "partition rc=$?"; show "$OUT/bench_partition_n1.json"
     timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8.json" 2>&1 | tail -3 | cut -c1-600
     ;;
+  s6)
+    # Round-5 session 6: the driver's SCALE launch form at N = 1 (torch.distributed.run -> RCCL group of one rank): stdout
+    # must carry the JSON line and NOTHING else (RCCL prints a banner to the C-level stdout); the same for --mode partition.
+    timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_torchrun_n1.json" 2> "$OUT/bench_torchrun_n1.err"; echo "torchrun bench rc=$?"
+    python - "$OUT/bench_torchrun_n1.json" <<'PY'
+import json, sys
+raw = open(sys.argv[1]).read()
+lines = [l for l in raw.splitlines() if l.strip()]
+print("stdout lines:", len(lines)); j = json.loads(raw); print("ONE JSON document on stdout:", j["n_gpus"], round(j["ms_per_step"], 3), j["config"]["parallelism"])
+PY
+    timeout 600 python bench.py --mode partition --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_partition_n1.json" 2> "$OUT/bench_partition.err"; echo "partition rc=$?"
+    python - "$OUT/bench_partition_n1.json" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read()); print("partition: ONE JSON document on stdout:", round(j["ms_per_step"], 3), j["roofline"]["exchange"]["device_ms_per_step"], j["output_finite"])
+PY
+    grep -c "RCCL version" "$OUT/bench_partition.err" "$OUT/bench_torchrun_n1.err"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

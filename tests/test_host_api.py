@@ -788,3 +788,55 @@ def test_wrappers_pass_host_datasets_through_when_there_is_no_gpu_predictor():
   assert seen == [True, True]
   Inner._device = "cuda:0"
   assert predictor_base.device_of(chain) == "cuda:0"
+
+
+def test_fused_rollout_recognises_the_demo_stack_and_nothing_else():
+  """rollout._fused_stack (round 5): which `predictor_fn`s get the fused device loop underneath
+  chunked_prediction*.  Pure host logic -- no GPU: a GraphCast object only carries its device NAME until its first
+  step.  Recognised: [autoregressive.Predictor(] InputsAndResiduals( [Bfloat16Cast(] GraphCast on a cuda device, given
+  as rollout.as_predictor_fn (trusted), inside a closure, a module-level lambda's global or a functools.partial
+  (cross-checked on the first chunk).  Anything else -- a toy predictor, a CPU model, an unknown wrapper in the chain, a
+  bare GraphCast (no residual algebra to fuse), two different stacks in one closure -- is left to the generic loop."""
+  import functools
+  from graphcast_amd import casting, graphcast as gcm, normalization
+  cfg = gcm.ModelConfig(resolution=6.0, mesh_size=2, latent_size=512, gnn_msg_steps=2, hidden_layers=1,
+                        radius_query_fraction_edge_length=0.6)
+  model = gcm.GraphCast(cfg, gcm.TASK_13, device="cuda:0")
+  stats = synthetic.make_stats(gcm.TASK_13)
+  mean, std, dstd = stats
+  stack = normalization.InputsAndResiduals(model, std, mean, dstd)
+  found = rollout._fused_stack(rollout.as_predictor_fn(stack))
+  assert found is not None and found.model is model and not found.verify and found.tier is None and not found.time_leading
+  assert found.std is stack._state_stats[0] and found.mean is stack._state_stats[1] and found.dstd is stack._residual_stats[0]
+  # closures, partials: found, but to be cross-checked
+  for fn in (lambda rng, **kw: stack(**kw),
+             functools.partial(lambda predictor, rng, **kw: predictor(**kw), stack),
+             functools.partial(lambda rng, predictor=None, **kw: predictor(**kw), predictor=stack)):
+    found = rollout._fused_stack(fn)
+    assert found is not None and found.model is model and found.verify
+  # the reference's full chain: autoregressive outermost (time-leading outputs), Bfloat16Cast inside the normalisation
+  full = autoregressive.Predictor(normalization.InputsAndResiduals(casting.Bfloat16Cast(model), std, mean, dstd))
+  found = rollout._fused_stack(rollout.as_predictor_fn(full))
+  assert found is not None and found.time_leading and found.tier == "bf16" and found.model is model
+  off = normalization.InputsAndResiduals(casting.Bfloat16Cast(model, enabled=False), std, mean, dstd)
+  assert rollout._fused_stack(rollout.as_predictor_fn(off)).tier is None
+  # a closure that holds the stack AND its inner model still has ONE outermost stack
+  assert rollout._fused_stack(lambda rng, **kw: (model, stack)[1](**kw)).model is model
+  # not recognised
+  toy = _toy()
+  assert rollout._fused_stack(lambda rng, **kw: toy(**kw)) is None
+  assert rollout._fused_stack(rollout.as_predictor_fn(model)) is None                     # bare GraphCast
+  assert rollout._fused_stack(rollout.as_predictor_fn(normalization.InputsAndResiduals(toy, std, mean, dstd))) is None
+  cpu_model = gcm.GraphCast(cfg, gcm.TASK_13, device="cpu")
+  assert rollout._fused_stack(rollout.as_predictor_fn(normalization.InputsAndResiduals(cpu_model, std, mean, dstd))) is None
+
+  class Extra(predictor_base.Predictor):                                                  # an unknown wrapper in the chain
+    def __init__(self, p):
+      self._predictor = p
+    def __call__(self, inputs, targets_template, forcings, **kw):
+      return self._predictor(inputs, targets_template, forcings, **kw)
+  assert rollout._fused_stack(rollout.as_predictor_fn(Extra(stack))) is None
+  assert rollout._fused_stack(rollout.as_predictor_fn(normalization.InputsAndResiduals(Extra(model), std, mean, dstd))) is None
+  other = normalization.InputsAndResiduals(gcm.GraphCast(cfg, gcm.TASK_13, device="cuda:0"), std, mean, dstd)
+  assert rollout._fused_stack(lambda rng, **kw: (stack if rng else other)(**kw)) is None  # two stacks: ambiguous
+  assert rollout._fused_stack(print) is None and rollout._fused_stack(None) is None
