@@ -846,7 +846,6 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
 // The eight-wave "helper waves" form of the same launch (csrc/rowmlp_half.inc: rowmlp16d_kernel): ONE persistent
 // workgroup per CU.  gc_rowmlp_desc.flags GC_WG_HELPERS asks for it per launch, GCAST_HELPERS=1|0 (read once) for a
 // whole process.
-bool g_d_attr_set[3][4] = {};
 int half_helpers_default() {
   static const int v = [] {
     const char* e = std::getenv("GCAST_HELPERS");
@@ -855,17 +854,18 @@ int half_helpers_default() {
   return v;
 }
 
-template <int MODE, int ONEPASS = 0>
-int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
+template <int MODE, int ONEPASS, bool HST>
+int launch_rowmlp_half_d2(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = (kHLdsFloats + kHSlotFloats) * sizeof(float);     // + the parked accumulators (LDS, not the scratch slots)
-  if (!g_d_attr_set[MODE][ONEPASS]) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16d_kernel<MODE, ONEPASS>),
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16d_kernel<MODE, ONEPASS, HST>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
       return GC_ELAUNCH;
     }
-    g_d_attr_set[MODE][ONEPASS] = true;
+    attr_set = true;
   }
   const int tiles = (d.n_rows + kHRows - 1) / kHRows;
   const int cap = half_grid_cap() < GC_SCRATCH_SLOTS / 2 ? half_grid_cap() : GC_SCRATCH_SLOTS / 2;   // one workgroup per CU
@@ -874,8 +874,19 @@ int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
   if (half_tile_xcd()) dd.flags |= GC_TILE_XCD;
   if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
   apply_prio(dd);
-  hipLaunchKernelGGL((rowmlp16d_kernel<MODE, ONEPASS>), dim3(grid), dim3(512), lds, s, dd);
+  hipLaunchKernelGGL((rowmlp16d_kernel<MODE, ONEPASS, HST>), dim3(grid), dim3(512), lds, s, dd);
   return check_launch("rowmlp16d_kernel");
+}
+
+// HST (round 5): an edge update that STORES its rows (segment-sum + out) hands residual + store to the staging waves
+// (csrc/rowmlp_half.inc: hstore) -- its own instantiation, chosen here.
+template <int MODE, int ONEPASS = 0>
+int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
+  if constexpr (MODE == GC_MODE_MLP_LN) {
+    static const bool hst_on = [] { const char* e = std::getenv("GCAST_HELPER_STORE"); return !e || std::atoi(e) != 0; }();
+    if (hst_on && d.seg && d.out) return launch_rowmlp_half_d2<MODE, ONEPASS, true>(d, s);
+  }
+  return launch_rowmlp_half_d2<MODE, ONEPASS, false>(d, s);
 }
 
 bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};

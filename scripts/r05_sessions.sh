@@ -81,5 +81,17 @@ j = json.loads(open(sys.argv[1]).read()); print("partition: ONE JSON document on
 PY
     grep -c "RCCL version" "$OUT/bench_partition.err" "$OUT/bench_torchrun_n1.err"
     ;;
+  s7)
+    # Round-5 session 7: the eight-wave form's staging waves take residual + store of the edge updates (HST): parity gate
+    # (per-launch tests run both kernel forms against each other; the whole step with every launch in the eight-wave
+    # form against the oracle), then same-session A/B of the step.
+    GCAST_HELPERS=1 timeout 300 python -m pytest tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=120 2>&1 | tail -3 | tee "$OUT/pytest_rowmlp_helpers.log"
+    gate "$OUT/pytest_rowmlp_helpers.log" "per-launch parity (GCAST_HELPERS=1)"
+    timeout 300 python -m pytest tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=120 2>&1 | tail -3 | tee "$OUT/pytest_rowmlp.log"
+    gate "$OUT/pytest_rowmlp.log" "per-launch parity"
+    GCAST_HELPERS=1 timeout 400 python -m pytest tests/test_step_gpu.py tests/test_rollout_gpu.py -m gpu -q -x --timeout=200 2>&1 | tail -3 | tee "$OUT/pytest_step_helpers.log"
+    gate "$OUT/pytest_step_helpers.log" "step parity (GCAST_HELPERS=1)"
+    bash scripts/session.sh bench-ab r05_s7 "GCAST_HELPERS=0" "GCAST_HELPERS=1 GCAST_HELPER_STORE=0" "GCAST_HELPERS=1" "GCAST_HELPERS=0"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
