@@ -18,6 +18,9 @@
 // read as conflict-free ds_read_b128 (slot index == n mod 16 within a lane group).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -854,7 +857,7 @@ int half_helpers_default() {
   return v;
 }
 
-template <int MODE, int ONEPASS, bool HST>
+template <int MODE, int ONEPASS, int HST>
 int launch_rowmlp_half_d2(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = (kHLdsFloats + kHSlotFloats) * sizeof(float);     // + the parked accumulators (LDS, not the scratch slots)
   static bool attr_set = false;
@@ -883,10 +886,17 @@ int launch_rowmlp_half_d2(const gc_rowmlp_desc& d, hipStream_t s) {
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
   if constexpr (MODE == GC_MODE_MLP_LN) {
-    static const bool hst_on = [] { const char* e = std::getenv("GCAST_HELPER_STORE"); return !e || std::atoi(e) != 0; }();
-    if (hst_on && d.seg && d.out) return launch_rowmlp_half_d2<MODE, ONEPASS, true>(d, s);
+    // GCAST_HELPER_STORE=0|1|2 (read once; A/B): 0 = the staging waves only stage, 1 = + residual / store, 2 (default)
+    // = + the gather of the next tile's addends, where the launch has the shape for it (two-pass, b1 + g0 + g1)
+    static const int hst_max = [] { const char* e = std::getenv("GCAST_HELPER_STORE"); return e ? std::atoi(e) : 2; }();
+    if (hst_max >= 1 && d.seg && d.out) {
+      if constexpr (ONEPASS == 0)
+        if (hst_max >= 2 && d.g0 && d.g1 && !d.d && d.b1 && d.k0 + d.k1 > 0)
+          return launch_rowmlp_half_d2<MODE, ONEPASS, 2>(d, s);
+      return launch_rowmlp_half_d2<MODE, ONEPASS, 1>(d, s);
+    }
   }
-  return launch_rowmlp_half_d2<MODE, ONEPASS, false>(d, s);
+  return launch_rowmlp_half_d2<MODE, ONEPASS, 0>(d, s);
 }
 
 bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};

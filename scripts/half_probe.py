@@ -301,15 +301,15 @@ def main():
         row.setdefault(tag, []).append(ms)
     # results of every extra build against the in-tree half-N library (same inputs): max |diff| of `og` / `agg`
     check = {}
-    if name in ("proc_edge", "node_grid") and len(libs) > 2:
+    if name in ("proc_edge", "node_grid") and len(libs) > 1:
       def run_once(lib, layout):
         d, _, _ = make(layout)
         og.zero_(); agg.zero_()
         assert lib.gc_rowmlp(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0, lib.gc_last_error()
         torch.cuda.synchronize()
         return og.clone(), agg.clone()
-      ref_o, ref_a = run_once(libs[1][1], libs[1][2])
-      for tag, lib, layout in libs[2:]:
+      ref_o, ref_a = run_once(libs[0][1], libs[0][2])
+      for tag, lib, layout in libs[1:]:
         o, a = run_once(lib, layout)
         check[tag] = {"out_max_abs_diff": float((o - ref_o).abs().max()), "agg_max_abs_diff": float((a - ref_a).abs().max()),
                       "out_abs_max": float(ref_o.abs().max())}
@@ -318,7 +318,7 @@ def main():
       if tag not in row:
         continue
       ms = float(np.median(row[tag]))
-      d, rows, flop = make(nat.LAYOUT_CHUNKED)
+      d, rows, flop = make(nat.LAYOUT_HALF)
       out[tag] = {"ms": round(ms, 4), "ms_all": [round(v, 4) for v in row[tag]],
                   "us_per_tile_per_cu": round(ms * 1e3 / (((rows + 63) // 64) / 256.0), 2),
                   "algorithmic_tflops": round(flop / ms / 1e9, 1)}

@@ -93,5 +93,25 @@ PY
     gate "$OUT/pytest_step_helpers.log" "step parity (GCAST_HELPERS=1)"
     bash scripts/session.sh bench-ab r05_s7 "GCAST_HELPERS=0" "GCAST_HELPERS=1 GCAST_HELPER_STORE=0" "GCAST_HELPERS=1" "GCAST_HELPERS=0"
     ;;
+  s8)
+    # Round-5 session 8: upper bound of "the staging waves gather the next tile's addends" -- a profiling library whose
+    # multiplying waves skip the gather (results wrong), processor-edge shape, eight-wave form with HST, against the
+    # shipped library in both forms.
+    GCAST_HELPERS=1 HALF_BUILDS="nogather:-DGC_H_NOGATHER=1" PROBE_SHAPES=proc_edge timeout 400 python -u scripts/half_probe.py --rounds 3 --iters 10 --out "$OUT/probe_helpers.json" 2>&1 | grep -v amdgpu.ids | cut -c1-900 | tail -3
+    GCAST_HELPERS=0 PROBE_SHAPES=proc_edge timeout 300 python -u scripts/half_probe.py --rounds 3 --iters 10 --out "$OUT/probe_pair.json" 2>&1 | grep -v amdgpu.ids | cut -c1-500 | tail -2
+    ;;
+  s9)
+    # Round-5 session 9: HST == 2 (the staging waves gather the next tile's addends): the processor-edge launch in both
+    # kernel forms, bit for bit, under a short timeout (a barrier mismatch between the roles would hang the launch).
+    timeout 240 python -m pytest tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=100 -k "processor_edge_update_in_both" 2>&1 | tail -15 | cut -c1-300 | tee "$OUT/pytest_proc_edge.log"
+    ;;
+  s10)
+    # Round-5 session 10: HST == 2 on the whole step: parity gates with every launch in the eight-wave form, then the A/B.
+    GCAST_HELPERS=1 timeout 300 python -m pytest tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=120 2>&1 | tail -3 | tee "$OUT/pytest_rowmlp_helpers.log"
+    gate "$OUT/pytest_rowmlp_helpers.log" "per-launch parity (GCAST_HELPERS=1)"
+    GCAST_HELPERS=1 timeout 400 python -m pytest tests/test_step_gpu.py tests/test_rollout_gpu.py tests/test_plan_gpu.py -m gpu -q -x --timeout=200 2>&1 | tail -3 | tee "$OUT/pytest_step_helpers.log"
+    gate "$OUT/pytest_step_helpers.log" "step parity (GCAST_HELPERS=1)"
+    bash scripts/session.sh bench-ab r05_s10 "GCAST_HELPERS=0" "GCAST_HELPERS=1 GCAST_HELPER_STORE=1" "GCAST_HELPERS=1" "GCAST_HELPERS=0" "GCAST_HELPERS=1"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

@@ -685,3 +685,74 @@ def test_small_launches_give_the_same_bits_in_both_kernel_forms(dev):
   _chain_stage(d, 0, tws, nat.CHAIN_ROWS, out=o_s, ldo=D)
   _chain_stage(d, 1, twr, nat.CHAIN_ROWS, out=o_r, ldo=D)
   run_all_forms(d, [o, o_s, o_r])
+
+
+@pytest.mark.parametrize("n_recv", [300, 9000])
+def test_processor_edge_update_in_both_kernel_forms(dev, n_recv):
+  """The processor's edge update as the step launches it from step 1 on (engine: proc_edge -- typed_graph_net.py:431-453
+  after the pre-gather split): e.W_e (a layer-1 GEMM over the edge rows) + b1 + (h.W_s)[senders] + (h.W_r)[receivers]
+  -> MLP -> LayerNorm -> segment-sum, residual and output IN PLACE on the edge rows.  Round 5: in the eight-wave form
+  the STAGING waves take residual + store (from the segment-sum's staging tile) and gather the NEXT tile's addends
+  while the multiplying waves are in this tile's GEMMs, handing them over through LDS at the top of the next tile
+  (csrc/rowmlp_half.inc: HST == 2).  Same bits as the four-wave form -- rows and aggregate -- with one tile per
+  workgroup (n_recv 300) and with several tiles per workgroup, statically walked and handed out by the tile queue
+  (9000: 700+ tiles on 256 workgroups); and against the float64 oracle."""
+  _half_only()
+  rng = np.random.default_rng(n_recv)
+  deg = rng.integers(2, 9, n_recv)
+  deg[7] = 300
+  receivers = rng.permutation(np.repeat(np.arange(n_recv), deg))
+  n_send = 120
+  senders = rng.integers(0, n_send, len(receivers))
+  pk = packing.pack_edges(senders, receivers, n_recv)
+  p = _mlp_ln_case(rng, pk.n_rows, D, 0)
+  gs = rng.standard_normal((n_send, D)).astype(np.float32)
+  gr = rng.standard_normal((n_recv, D)).astype(np.float32)
+  t = dict(gs=up(gs, dev), gr=up(gr, dev), b1=up(p["b1"], dev), w1=up(pw1(p["w1"]), dev),
+           w2=up(pw2(p["w2"]), dev), b2=up(p["b2"], dev), sc=up(p["scale"], dev), of=up(p["offset"], dev),
+           snd=up(pk.senders, dev, np.int32), rcv=up(pk.receivers, dev, np.int32), flags=up(pk.tile_flags, dev, np.int32))
+  e0 = up(p["a0"], dev)
+  e = torch.empty_like(e0)
+  agg = torch.empty((n_recv, D), device=dev)
+  partial = torch.empty((2 * pk.n_rows // 64, D), device=dev)
+  queue = torch.zeros((2,), dtype=torch.int32, device=dev)
+  d = new_desc(nat.MODE_MLP_LN, pk.n_rows)
+  d.a0, d.lda0, d.k0, d.w1p = e.data_ptr(), D, D, t["w1"].data_ptr()
+  d.g0, d.idx0, d.g1, d.idx1 = t["gs"].data_ptr(), t["snd"].data_ptr(), t["gr"].data_ptr(), t["rcv"].data_ptr()
+  d.b1, d.w2p, d.b2, d.n2 = t["b1"].data_ptr(), t["w2"].data_ptr(), t["b2"].data_ptr(), D
+  d.ln_scale, d.ln_offset = t["sc"].data_ptr(), t["of"].data_ptr()
+  d.res, d.ldres, d.out, d.ldo = e.data_ptr(), D, e.data_ptr(), D
+  d.seg, d.tile_flags = t["rcv"].data_ptr(), t["flags"].data_ptr()
+  d.agg, d.partial = agg.data_ptr(), partial.data_ptr()
+  lib = nat.lib()
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  fix = [up(x, dev, np.int32) for x in (pk.fix_recv, pk.fix_t0, pk.fix_t1)] if len(pk.fix_recv) else None
+
+  def pipeline(flags, with_queue):
+    e.copy_(e0)
+    agg.fill_(float("nan")); partial.fill_(float("nan"))
+    d.flags = flags
+    d.tile_queue = queue.data_ptr() if with_queue else None
+    apply_scales(d)
+    nat.check(lib.gc_rowmlp(ctypes.byref(d), stream), "gc_rowmlp")
+    if fix is not None:
+      nat.check(lib.gc_seg_fixup(len(pk.fix_recv), fix[0].data_ptr(), fix[1].data_ptr(), fix[2].data_ptr(),
+                                 partial.data_ptr(), agg.data_ptr(), stream), "gc_seg_fixup")
+    torch.cuda.synchronize()
+    assert queue.tolist() == [0, 0]
+    return e.clone(), agg.clone()
+
+  ref_e, ref_agg = pipeline(nat.WG_NO_HELPERS, False)
+  ok = pk.receivers >= 0
+  extra = gs[np.maximum(pk.senders, 0)].astype(np.float64) + gr[np.maximum(pk.receivers, 0)]
+  e_new = _mlp_ln_want(p, extra)
+  assert_close(ref_e.cpu().numpy()[ok], (p["a0"].astype(np.float64) + e_new)[ok], "processor edge rows (four-wave form)")
+  want = ognn.segment_sum(e_new[ok], pk.receivers[ok], n_recv)
+  has = np.bincount(pk.receivers[ok], minlength=n_recv) > 0
+  got = ref_agg.cpu().numpy()
+  assert np.linalg.norm(got[has] - want[has]) <= 2 * REL_RMSE_TOL[_PREC] * np.linalg.norm(want[has])
+  for flags, with_queue in ((nat.WG_HELPERS, False), (nat.WG_HELPERS | nat.TILE_QUEUE_ANY, True),
+                            (nat.WG_NO_HELPERS | nat.TILE_QUEUE_ANY, True), (nat.WG_HELPERS, False)):
+    got_e, got_agg = pipeline(flags, with_queue)
+    assert torch.equal(got_e, ref_e), (flags, with_queue, float((got_e - ref_e).abs().max()))
+    assert torch.equal(got_agg[torch.from_numpy(has).to(dev)], ref_agg[torch.from_numpy(has).to(dev)]), (flags, with_queue)
