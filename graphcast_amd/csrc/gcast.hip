@@ -822,7 +822,18 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
     return (!e || std::atoi(e) != 0) && !(h && std::atoi(h) == 0);
   }();
   const bool small = small_rule && !d.g0 && !d.seg && (d.n_rows + kHRows - 1) / kHRows <= GC_SCRATCH_SLOTS / 2;
-  if ((d.flags & GC_WG_HELPERS) || (!(d.flags & GC_WG_NO_HELPERS) && (half_helpers_default() || small)))
+  // Round 5: the processor's edge update from step 1 on (two-pass, b1 + g0 + g1, segment-sum, rows stored) runs in the
+  // eight-wave form too -- its staging waves take residual + store and gather the next tile's addends (rowmlp_half.inc:
+  // HST == 2): 19.45 against 19.9 ms per step as two four-wave workgroups per CU (profiles/r05_s10_*), the same bits.
+  // GCAST_HELPERS_EDGE=0 (or GCAST_HELPERS=0) keeps the four-wave form (A/B).
+  static const bool edge_rule = [] {
+    const char* e = std::getenv("GCAST_HELPERS_EDGE");
+    const char* h = std::getenv("GCAST_HELPERS");
+    return (!e || std::atoi(e) != 0) && !(h && std::atoi(h) == 0);
+  }();
+  const bool edge = edge_rule && MODE == GC_MODE_MLP_LN && ONEPASS == 0 && d.seg && d.out && d.g0 && d.g1 && !d.d && d.b1 &&
+                    d.k0 + d.k1 > 0 && (d.n_rows + kHRows - 1) / kHRows > GC_SCRATCH_SLOTS / 2;
+  if ((d.flags & GC_WG_HELPERS) || (!(d.flags & GC_WG_NO_HELPERS) && (half_helpers_default() || small || edge)))
     return launch_rowmlp_half_d<MODE, ONEPASS>(d, s);
   const size_t lds = kHLdsFloats * sizeof(float);
   if (!g_h_attr_set[MODE][ONEPASS]) {

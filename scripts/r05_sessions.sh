@@ -113,5 +113,14 @@ PY
     gate "$OUT/pytest_step_helpers.log" "step parity (GCAST_HELPERS=1)"
     bash scripts/session.sh bench-ab r05_s10 "GCAST_HELPERS=0" "GCAST_HELPERS=1 GCAST_HELPER_STORE=1" "GCAST_HELPERS=1" "GCAST_HELPERS=0" "GCAST_HELPERS=1"
     ;;
+  s11)
+    # Round-5 session 11: HST == 2 without its hand-over barrier, shipped by default on the processor edge update: parity,
+    # then A/B against the four-wave form, and the wave priorities again now that the staging waves execute VALU work.
+    timeout 300 python -m pytest tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=120 2>&1 | tail -3 | tee "$OUT/pytest_rowmlp.log"
+    gate "$OUT/pytest_rowmlp.log" "per-launch parity"
+    GCAST_HELPERS=1 timeout 300 python -m pytest tests/test_rowmlp_gpu.py tests/test_step_gpu.py -m gpu -q -x --timeout=120 2>&1 | tail -3 | tee "$OUT/pytest_helpers.log"
+    gate "$OUT/pytest_helpers.log" "parity (GCAST_HELPERS=1)"
+    bash scripts/session.sh bench-ab r05_s11 "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1" "GCAST_HELPERS_EDGE=1 GCAST_PRIO=3,0,0" "GCAST_HELPERS_EDGE=1 GCAST_PRIO=2,0,0" "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
