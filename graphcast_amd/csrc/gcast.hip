@@ -822,14 +822,17 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
     return (!e || std::atoi(e) != 0) && !(h && std::atoi(h) == 0);
   }();
   const bool small = small_rule && !d.g0 && !d.seg && (d.n_rows + kHRows - 1) / kHRows <= GC_SCRATCH_SLOTS / 2;
-  // Round 5: the processor's edge update from step 1 on (two-pass, b1 + g0 + g1, segment-sum, rows stored) runs in the
-  // eight-wave form too -- its staging waves take residual + store and gather the next tile's addends (rowmlp_half.inc:
-  // HST == 2): 19.45 against 19.9 ms per step as two four-wave workgroups per CU (profiles/r05_s10_*), the same bits.
-  // GCAST_HELPERS_EDGE=0 (or GCAST_HELPERS=0) keeps the four-wave form (A/B).
+  // Round 5: the processor's edge update from step 1 on (two-pass, b1 + g0 + g1, segment-sum, rows stored) CAN run in
+  // the eight-wave form -- its staging waves then take residual + store and gather the next tile's addends
+  // (rowmlp_half.inc: HST == 2), the same bits -- and is 2.4 % faster in it: 19.41 against 19.87 ms per step
+  // (profiles/r05_s11_*).  OPT-IN (GCAST_HELPERS_EDGE=1), because the step does not get faster: the launch that follows
+  // (the processor's node update) slows down by twice what was gained (5.69 -> 6.64 ms per step), whole step 53.02 ->
+  // 53.22 ms -- the part runs at its power limit (1367 W at 1.94 GHz, profiles/r05_s12_*) and a launch that finishes the
+  // same work sooner leaves the next one a lower clock.  DESIGN.md section 9.14.
   static const bool edge_rule = [] {
     const char* e = std::getenv("GCAST_HELPERS_EDGE");
     const char* h = std::getenv("GCAST_HELPERS");
-    return (!e || std::atoi(e) != 0) && !(h && std::atoi(h) == 0);
+    return e && std::atoi(e) != 0 && !(h && std::atoi(h) == 0);
   }();
   const bool edge = edge_rule && MODE == GC_MODE_MLP_LN && ONEPASS == 0 && d.seg && d.out && d.g0 && d.g1 && !d.d && d.b1 &&
                     d.k0 + d.k1 > 0 && (d.n_rows + kHRows - 1) / kHRows > GC_SCRATCH_SLOTS / 2;

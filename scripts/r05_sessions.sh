@@ -122,5 +122,10 @@ PY
     gate "$OUT/pytest_helpers.log" "parity (GCAST_HELPERS=1)"
     bash scripts/session.sh bench-ab r05_s11 "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1" "GCAST_HELPERS_EDGE=1 GCAST_PRIO=3,0,0" "GCAST_HELPERS_EDGE=1 GCAST_PRIO=2,0,0" "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1"
     ;;
+  s12)
+    # Round-5 session 12: is the step power-bound?  Socket power / cap / shader clock polled while the step runs.
+    which amd-smi rocm-smi
+    timeout 300 python scripts/power_probe.py --seconds 6 --out "$OUT/power_probe.json" 2>&1 | grep -v amdgpu.ids | cut -c1-1500 | tail -4
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
