@@ -450,6 +450,40 @@ def main():
     emit_line(json.dumps(line))              # the ONE line on stdout
 
 
+class _PowerPoll:
+  """Socket power and shader clock of GPU 0 while something runs (scripts/power_probe.py's reader in a thread)."""
+
+  def __init__(self):
+    import threading
+    self._stop, self._samples = threading.Event(), []
+    self._thread = threading.Thread(target=self._run, daemon=True)
+
+  def _run(self):
+    try:
+      sys.path.insert(0, os.path.join(ROOT, "scripts"))
+      import power_probe
+      while not self._stop.is_set():
+        s = power_probe.read_once()
+        s.pop("raw", None)
+        self._samples.append(s)
+        time.sleep(0.05)
+    except Exception as e:      # noqa: BLE001  (a missing tool must not cost the bench line)
+      self._samples.append({"errors": [repr(e)]})
+
+  def start(self):
+    self._thread.start()
+
+  def stop(self):
+    self._stop.set()
+    self._thread.join(timeout=10)
+    pw = sorted(s["power_w"] for s in self._samples if "power_w" in s)
+    ck = sorted(s["sclk_mhz"] for s in self._samples if "sclk_mhz" in s)
+    if not pw:
+      return {"unavailable": sorted({e for s in self._samples for e in s.get("errors", [])})[:2]}
+    return {"socket_w_median": pw[len(pw) // 2], "socket_w_max": pw[-1], "sclk_mhz_median": ck[len(ck) // 2] if ck else None,
+            "samples": len(pw), "board_power_w": 1400, "tool": "amd-smi metric --power --clock (scripts/power_probe.py)"}
+
+
 def stage_table(engine, x, y, iters):
   """Per-stage totals of one step of `engine`: per-launch durations by HIP events on the launch stream
   (gc_time_program), executed FLOPs and weight-stream bytes of every launch, summed by stage tag."""
@@ -530,11 +564,17 @@ def rollout_extra(model, task, lat, lon, n_steps):
   roll = rollout_device.DeviceRollout(model, std, mean, dstd)
   roll.run(inputs, template.isel(time=slice(0, 1)), forcings.isel(time=slice(0, 1)), keep_trajectory=False)   # tables, warm-up
   torch.cuda.synchronize()
+  # socket power / shader clock polled (amd-smi, every ~50 ms, another thread) while the 40 steps run: the step sits at
+  # the part's power limit -- this is where the line shows it
+  power = _PowerPoll()
+  power.start()
   last = roll.run(inputs, template, forcings, keep_trajectory=False)
   torch.cuda.synchronize()
+  power_report = power.stop()
   loop_ms = roll.last_loop_ms()
   return {"steps": n_steps, "ms_per_step": loop_ms / n_steps, "steps_per_second": 1e3 * n_steps / loop_ms,
           "advance_state_ms": roll.advance_ms(), "finite": bool(torch.isfinite(last).all().item()),
+          "power": power_report,
           "what": f"{n_steps} x 6 h autoregressive steps, state + forcings resident in HBM (DeviceRollout), device-loop "
                   "time by HIP events; parity of this loop: tests/test_rollout40_fullsize_gpu.py"}
 

@@ -62,3 +62,9 @@ if [ "${DO_SQ:-1}" = "1" ]; then
 import json; j=json.load(open('$OUT/sq_by_stage.json')); print({k: {m: round(v[m], 3) for m in ('mfma_busy_per_simd', 'wave_waiting', 'wave_waiting_on_lds', 'lds_bank_conflict') if m in v} for k, v in j.items() if not k.startswith('_')})"
 fi
 find "$OUT" -type f -size +8M -delete
+# round 5: the step at the part's power limit (socket power / shader clock polled while it runs), the partition-mode
+# line at N = 1 (per-rank roofline, exchange probe) and the driver's SCALE launch form at N = 1
+echo "== power probe"; timeout 300 python scripts/power_probe.py --seconds 6 --out "$OUT/power_probe.json" 2>&1 | grep -v amdgpu.ids | head -1 | cut -c1-400
+echo "== bench --mode partition (N = 1)"; timeout 600 python bench.py --mode partition --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_partition_n1.json" 2>> "$OUT/bench.err"; echo "rc=$?"; cut -c1-200 "$OUT/bench_partition_n1.json"
+echo "== bench under torch.distributed.run (N = 1)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_torchrun_n1.json" 2>> "$OUT/bench.err"; echo "rc=$? lines=$(wc -l < "$OUT/bench_torchrun_n1.json")"
+
