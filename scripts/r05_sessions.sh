@@ -127,5 +127,18 @@ PY
     which amd-smi rocm-smi
     timeout 300 python scripts/power_probe.py --seconds 6 --out "$OUT/power_probe.json" 2>&1 | grep -v amdgpu.ids | cut -c1-1500 | tail -4
     ;;
+  s13)
+    # Round-5 session 13: the shader clock per stage (SQ_WAVE_CYCLES / duration of the persistent launches) with the
+    # processor edge update as two four-wave workgroups per CU and in the eight-wave HST == 2 form: what the faster launch
+    # does to the one behind it.  (One --pmc pass each, kernel trace only: the node-safe combination.)
+    for E in 0 1; do
+      (cd /tmp && GCAST_HELPERS_EDGE=$E timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES --output-format csv -d "$OLDPWD/$OUT/pmc_edge$E" -o pmc -- \
+          python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-cross-check --rollout-steps 0 --op-timing-iters 1 > "$OLDPWD/$OUT/bench_edge$E.json" 2> "$OLDPWD/$OUT/bench_edge$E.err"); echo "pmc edge=$E rc=$?"
+      python scripts/clock_by_stage.py "$OUT/pmc_edge$E" > "$OUT/clock_by_stage_edge$E.json" 2>> "$OUT/errors.txt"
+      python -c "
+import json; j=json.load(open('$OUT/clock_by_stage_edge$E.json')); print({k: (v['clock_ghz'], v['ms_per_launch_under_the_counter_pass']) for k, v in j.items()})"
+    done
+    find "$OUT" -type f -size +8M -delete
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
