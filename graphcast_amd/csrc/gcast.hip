@@ -822,20 +822,24 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
     return (!e || std::atoi(e) != 0) && !(h && std::atoi(h) == 0);
   }();
   const bool small = small_rule && !d.g0 && !d.seg && (d.n_rows + kHRows - 1) / kHRows <= GC_SCRATCH_SLOTS / 2;
-  // Round 5: the processor's edge update from step 1 on (two-pass, b1 + g0 + g1, segment-sum, rows stored) CAN run in
-  // the eight-wave form -- its staging waves then take residual + store and gather the next tile's addends
-  // (rowmlp_half.inc: HST == 2), the same bits -- and is 2.4 % faster in it: 19.41 against 19.87 ms per step
-  // (profiles/r05_s11_*).  OPT-IN (GCAST_HELPERS_EDGE=1), because the step does not get faster: the launch that follows
-  // (the processor's node update) slows down by twice what was gained (5.69 -> 6.64 ms per step), whole step 53.02 ->
-  // 53.22 ms -- the part runs at its power limit (1367 W at 1.94 GHz, profiles/r05_s12_*) and a launch that finishes the
-  // same work sooner leaves the next one a lower clock.  DESIGN.md section 9.14.
-  static const bool edge_rule = [] {
+  // Round 5: the processor's edge update from step 1 on (two-pass, b1 + g0 + g1, segment-sum, rows stored) in the
+  // eight-wave form -- its staging waves take residual + store and gather the next tile's addends (rowmlp_half.inc:
+  // HST == 2), the same bits.  The launch is faster in it at every size (0.25 deg: 19.41 against 19.87 ms per step,
+  // profiles/r05_s11_*), but only SMALL launches turn that into a faster step: 1 deg (1,280 tiles) 8.69 -> 8.33 ms per
+  // step, an 8-way rank of the 0.25 deg partition (640 tiles) 11.79 -> 11.49 ms (profiles/r05_s14_*).  At the headline
+  // size (5,120 tiles) the part runs at its power limit -- 1367 W at 1.94 GHz, profiles/r05_s12_* -- and the launch
+  // behind a faster launch slows down by what was gained (5.69 -> 6.64 ms per step; whole step 53.02 -> 53.22 ms):
+  // DESIGN.md section 9.14.  Hence the rule: by default for launches of more than one and at most
+  // GC_HELPERS_EDGE_MAX_TILES tiles per ... launch; GCAST_HELPERS_EDGE=1 at every size, =0 (or GCAST_HELPERS=0) never.
+  static const int edge_rule = [] {
     const char* e = std::getenv("GCAST_HELPERS_EDGE");
     const char* h = std::getenv("GCAST_HELPERS");
-    return e && std::atoi(e) != 0 && !(h && std::atoi(h) == 0);
+    if (h && std::atoi(h) == 0) return 0;
+    return e ? (std::atoi(e) != 0 ? 2 : 0) : 1;
   }();
-  const bool edge = edge_rule && MODE == GC_MODE_MLP_LN && ONEPASS == 0 && d.seg && d.out && d.g0 && d.g1 && !d.d && d.b1 &&
-                    d.k0 + d.k1 > 0 && (d.n_rows + kHRows - 1) / kHRows > GC_SCRATCH_SLOTS / 2;
+  const int edge_tiles = (d.n_rows + kHRows - 1) / kHRows;
+  const bool edge = edge_rule != 0 && MODE == GC_MODE_MLP_LN && ONEPASS == 0 && d.seg && d.out && d.g0 && d.g1 && !d.d && d.b1 &&
+                    d.k0 + d.k1 > 0 && edge_tiles > GC_SCRATCH_SLOTS / 2 && (edge_rule == 2 || edge_tiles <= GC_HELPERS_EDGE_MAX_TILES);
   if ((d.flags & GC_WG_HELPERS) || (!(d.flags & GC_WG_NO_HELPERS) && (half_helpers_default() || small || edge)))
     return launch_rowmlp_half_d<MODE, ONEPASS>(d, s);
   const size_t lds = kHLdsFloats * sizeof(float);

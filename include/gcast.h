@@ -131,6 +131,10 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /
 #define GC_PRIO_GEMM_DEFAULT 1      /* (the GC_PREC_F16X3 kernels; GC_PREC_BF16: 0 -- measured, csrc/gcast.hip half_prio_flags) */
 #define GC_PRIO_OTHER_DEFAULT 0
 #define GC_PRIO_STAGE_DEFAULT 0
+#define GC_HELPERS_EDGE_MAX_TILES 2048   /* the processor's two-pass edge update runs in the eight-wave form with WORKING staging
+                                          * waves (residual + store, the next tile's addend gather) by default up to this
+                                          * many tiles: beyond it the part is at its power limit and the step gains nothing
+                                          * (csrc/gcast.hip: launch_rowmlp_half) */
 #define GC_TILE_XCD 16           /* GC_LAYOUT_HALF: tile -> workgroup map in which each XCD walks a contiguous eighth
                                   * of the launch's tiles (csrc/rowmlp_half.inc).  A speed choice only. */
 

@@ -140,5 +140,14 @@ import json; j=json.load(open('$OUT/clock_by_stage_edge$E.json')); print({k: (v[
     done
     find "$OUT" -type f -size +8M -delete
     ;;
+  s14)
+    # Round-5 session 14: the eight-wave HST forms where launches are SMALL (an 8-way rank's: 640 edge tiles, 80 node
+    # tiles -- not power-bound): the emulated 8-way partition and the 1 deg step with GCAST_HELPERS_EDGE=0|1; and the
+    # bf16 tier's power draw.
+    for E in 0 1; do
+      GCAST_HELPERS_EDGE=$E timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8_edge$E.json" 2>&1 | grep -v amdgpu | tail -1 | cut -c1-330
+    done
+    bash scripts/session.sh bench-ab r05_s14 --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check --rollout-steps 0 --config 1deg_13L_M5 -- "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1" "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
