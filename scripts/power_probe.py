@@ -4,7 +4,7 @@ whichever the box has) every ~100 ms while the step runs back to back for a few 
 next to the idle reading.  Evidence for DESIGN.md section 9.14 (round 5): a launch that gets faster per tile makes the
 NEXT launch slower by the same energy -- profiles/r05_s11_*.
 
-    python scripts/power_probe.py [--seconds 6] [--out gpurun_out/power_probe.json]
+    python scripts/power_probe.py [--seconds 6] [--precision bf16] [--config 1deg_13L_M5] [--out gpurun_out/power_probe.json]
 """
 import argparse
 import json
@@ -52,19 +52,23 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--seconds", type=float, default=6.0)
   ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "power_probe.json"))
+  ap.add_argument("--precision", default=None, choices=["f16x3", "f32", "bf16"])
+  ap.add_argument("--config", default="0.25deg_37L_M6")
   args = ap.parse_args()
   import numpy as np
   import torch
   import bench as B
   from graphcast_amd import graphcast as gc
   idle = read_once()
-  res, mesh_size, levels, gnn_steps = B.CONFIGS["0.25deg_37L_M6"]
-  c_out = gc.num_output_channels(gc.TASK)
+  res, mesh_size, levels, gnn_steps = B.CONFIGS[args.config]
+  task = {37: gc.TASK, 13: gc.TASK_13}[levels]
+  c_out = gc.num_output_channels(task)
   c_in = 2 * (5 + 6 * levels) + 2 * 5 + 2 + 5
   lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
   cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=512, gnn_msg_steps=gnn_steps, hidden_layers=1,
                        radius_query_fraction_edge_length=0.6)
-  model = gc.GraphCast(cfg, gc.TASK, params=B.fast_params(c_in, c_out, gnn_steps)).init_from_coordinates(lat, lon)
+  model = gc.GraphCast(cfg, task, params=B.fast_params(c_in, c_out, gnn_steps),
+                       precision=args.precision).init_from_coordinates(lat, lon)
   x = torch.from_numpy(np.random.default_rng(0).standard_normal((len(lat) * len(lon), 1, c_in), dtype=np.float32)).cuda()
   y = model.forward_grid_node_features(x)
   torch.cuda.synchronize()
@@ -93,7 +97,7 @@ def main():
   pw = [s["power_w"] for s in samples if "power_w" in s]
   ck = [s["sclk_mhz"] for s in samples if "sclk_mhz" in s]
   raw_idle = idle.pop("raw", "")
-  rep = {"idle": idle, "idle_raw_head": raw_idle[:1500], "steps": n, "ms_per_step": 1e3 * dt / n, "samples": len(samples),
+  rep = {"config": args.config, "precision": model._engine.precision, "idle": idle, "idle_raw_head": raw_idle[:1500], "steps": n, "ms_per_step": 1e3 * dt / n, "samples": len(samples),
          "power_w": {"min": min(pw), "median": sorted(pw)[len(pw) // 2], "max": max(pw)} if pw else None,
          "sclk_mhz": {"min": min(ck), "median": sorted(ck)[len(ck) // 2], "max": max(ck)} if ck else None,
          "cap_w": next((s["cap_w"] for s in samples if "cap_w" in s), idle.get("cap_w")),

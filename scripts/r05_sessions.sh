@@ -149,5 +149,30 @@ import json; j=json.load(open('$OUT/clock_by_stage_edge$E.json')); print({k: (v[
     done
     bash scripts/session.sh bench-ab r05_s14 --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check --rollout-steps 0 --config 1deg_13L_M5 -- "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1" "GCAST_HELPERS_EDGE=0" "GCAST_HELPERS_EDGE=1"
     ;;
+  s15)
+    # Round-5 session 15 (after the round-end session on the library with the edge rule): (a) the driver's bench command
+    # with the counter summaries of THIS library in profiles/current_* -- the line carries roofline.traffic / .pmc;
+    # (b) the step / launch / plan / partition / rollout suites with the processor edge update pinned to each kernel
+    # form (GCAST_HELPERS_EDGE=1: eight-wave HST form at every size; =0: the pair everywhere) -- the default rule mixes
+    # them by size; (c) power / clock while the bf16 tier and the 1 deg step run: which of them are power-bound.
+    timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
+    python - "$OUT/bench.json" <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])["roofline"]
+print("traffic", r.get("traffic"), "frac", round(r["frac"], 4), "pmc", str(r.get("pmc"))[:200])
+PY
+    for E in 1 0; do
+      GCAST_HELPERS_EDGE=$E timeout 900 python -m pytest tests/test_rowmlp_gpu.py tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_partition_gpu.py tests/test_rollout40_gpu.py tests/test_fullsize_gpu.py \
+          -m gpu -q -x --timeout=600 > "$OUT/pytest_edge$E.log" 2>&1; echo "pytest GCAST_HELPERS_EDGE=$E rc=$?"; tail -2 "$OUT/pytest_edge$E.log"
+      gate "$OUT/pytest_edge$E.log" "suite with GCAST_HELPERS_EDGE=$E"
+    done
+    timeout 300 python scripts/power_probe.py --precision bf16 --out "$OUT/power_probe_bf16.json" | head -1 | cut -c1-400
+    timeout 300 python scripts/power_probe.py --config 1deg_13L_M5 --out "$OUT/power_probe_1deg.json" | head -1 | cut -c1-400
+    timeout 300 python scripts/power_probe.py --out "$OUT/power_probe_f16x3.json" | head -1 | cut -c1-400
+    # (d) scripts/ubench/rows_per_fragment.hip: the same MFMA work per CU with half the weight stream / half the LDS
+    # fragment reads / half the operand reads, at the power limit (what comes next)
+    hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/rows_per_fragment.hip -o /tmp/rows_per_fragment && \
+      for V in 0 1 2 3 0 2 3; do timeout 60 /tmp/rows_per_fragment $V; done | tee "$OUT/rows_per_fragment.jsonl"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
