@@ -174,5 +174,20 @@ PY
     hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/rows_per_fragment.hip -o /tmp/rows_per_fragment && \
       for V in 0 1 2 3 0 2 3; do timeout 60 /tmp/rows_per_fragment $V; done | tee "$OUT/rows_per_fragment.jsonl"
     ;;
+  s16)
+    # Round-5 session 16: the SHIPPED default (no switches) where the edge rule applies -- the 1 deg step with a kernel
+    # trace (which kernel each stage's launches are), the emulated 8-way partition of the 0.25 deg step -- against
+    # GCAST_HELPERS_EDGE=0, same session.
+    bash scripts/session.sh bench-ab r05_s16 --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check --rollout-steps 0 --config 1deg_13L_M5 -- "" "GCAST_HELPERS_EDGE=0" "" "GCAST_HELPERS_EDGE=0"
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof_1deg" -o trace -- \
+        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-cross-check --rollout-steps 0 --op-timing-iters 1 --config 1deg_13L_M5 > "$OLDPWD/$OUT/prof_1deg_bench.json" 2> "$OLDPWD/$OUT/prof_1deg.err"); echo "rocprof rc=$?"
+    f=$(find "$OUT/prof_1deg" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { cut -c1-240 "$f" | head -12 | tee "$OUT/kernel_stats_1deg_head.csv"; }
+    for E in default 0; do
+      if [ "$E" = default ]; then unset GCAST_HELPERS_EDGE; else export GCAST_HELPERS_EDGE=$E; fi
+      timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8_edge_$E.json" 2>&1 | grep -v amdgpu | tail -1 | cut -c1-330
+    done
+    unset GCAST_HELPERS_EDGE
+    find "$OUT" -type f -size +8M -delete
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
