@@ -430,7 +430,8 @@ def main():
         "output_finite": finite,
         "formulation": (("half-N kernels, two persistent four-wave workgroups per CU, chained layers"
                          + (f"; launches without gather / segment-sum from {engine.helpers_min_rows} rows on as ONE eight-wave "
-                            "workgroup per CU (four multiplying + four weight-staging waves)"
+                            + ("workgroup per CU (four multiplying + four weight-staging waves)" if os.environ.get("GCAST_WIDE") == "0"
+                               else "workgroup per CU (the wide form: eight multiplying waves on one weight ring)")
                             if getattr(engine, "helpers_min_rows", 0) else "")) if getattr(engine, "fuse", False)
                         else "half-N kernels, two persistent workgroups per CU" if getattr(engine, "half", False)
                         else "chunked, one workgroup per CU"),

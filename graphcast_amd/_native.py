@@ -25,6 +25,7 @@ LATENT = 512
 TILE_MAP_XCD = 16                                 # GC_TILE_XCD
 TILE_QUEUE_ANY = 128                              # GC_TILE_QUEUE_ANY: the dynamic tile queue whenever a launch has a second round
 WG_HELPERS, WG_NO_HELPERS = 32, 64                # GC_WG_HELPERS / GC_WG_NO_HELPERS (eight-wave form of a GC_LAYOUT_HALF launch)
+WG_WIDE = 256                                     # GC_WG_WIDE (eight MULTIPLYING waves per CU on one weight ring; no segment-sum)
 TILE_ROWS = 64
 K_CHUNK = 32
 SCRATCH_SLOTS = 512                               # GC_SCRATCH_SLOTS: persistent workgroups of a GC_LAYOUT_HALF launch
@@ -146,7 +147,9 @@ def library_path(variant=None):
 # address and descriptor values around the prologue / epilogue), the bf16 tier 260.
 RESOURCE_LIMITS = {"rowmlp16h_kernel": dict(scratch=160, occupancy=2), "rowmlpbf_kernel": dict(scratch=320, occupancy=2),
                    # the eight-wave helper form (one 512-thread workgroup per CU = two waves per SIMD: the same 256-register budget)
-                   "rowmlp16d_kernel": dict(scratch=160, occupancy=2)}
+                   "rowmlp16d_kernel": dict(scratch=160, occupancy=2),
+                   # the wide form (eight multiplying waves, one workgroup per CU): the same budget again
+                   "rowmlp16w_kernel": dict(scratch=160, occupancy=2)}
 
 
 def check_resources(remarks, limits=None):

@@ -807,8 +807,17 @@ inline bool tile_queue_pays(const gc_rowmlp_desc& d, int tiles, int grid) {
   return d.tile_queue && (tiles >= GC_TILE_QUEUE_MIN_ROUNDS * grid || ((d.flags & GC_TILE_QUEUE_ANY) && tiles > grid));
 }
 
+template <int MODE>
+int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s);
+
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
+  // The wide form (csrc/rowmlp_half.inc: rowmlp16w_kernel; eight multiplying waves per CU on ONE weight ring): asked for
+  // per launch with GC_WG_WIDE -- the plan marks the big launches without gather or segment-sum (gcast_plan.inc: op_mlp).
+  // Two-pass GC_MODE_MLP_LN launches without a segment-sum only: elsewhere the flag is ignored (a speed choice).
+  if constexpr (MODE == GC_MODE_MLP_LN && ONEPASS == 0) {
+    if ((d.flags & GC_WG_WIDE) && !d.seg) return launch_rowmlp_half_w<MODE>(d, s);
+  }
   // Which form.  Asked for per launch (GC_WG_HELPERS / GC_WG_NO_HELPERS), or per process (GCAST_HELPERS); otherwise:
   // a launch of at most one tile per CU runs one four-wave workgroup per CU anyway -- for the node-side launches (no
   // gather, no segment-sum) the eight-wave form with its staging waves is faster per lone tile (1 deg step: processor
@@ -897,6 +906,30 @@ int launch_rowmlp_half_d2(const gc_rowmlp_desc& d, hipStream_t s) {
   apply_prio(dd);
   hipLaunchKernelGGL((rowmlp16d_kernel<MODE, ONEPASS, HST>), dim3(grid), dim3(512), lds, s, dd);
   return check_launch("rowmlp16d_kernel");
+}
+
+template <int MODE>
+int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s) {
+  const size_t lds = kHLdsFloats * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16w_kernel<MODE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+      return GC_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tiles = (d.n_rows + 2 * kHRows - 1) / (2 * kHRows);          // 128-row tiles
+  const int cap = half_grid_cap() < GC_SCRATCH_SLOTS / 2 ? half_grid_cap() : GC_SCRATCH_SLOTS / 2;   // one workgroup per CU, two slots each
+  const int grid = tiles < cap ? tiles : cap;
+  gc_rowmlp_desc dd = d;
+  dd.flags &= ~GC_TILE_XCD;
+  if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
+  apply_prio(dd);
+  hipLaunchKernelGGL((rowmlp16w_kernel<MODE>), dim3(grid), dim3(512), lds, s, dd);
+  return check_launch("rowmlp16w_kernel");
 }
 
 // HST (round 5): an edge update that STORES its rows (segment-sum + out) hands residual + store to the staging waves
@@ -1300,7 +1333,7 @@ const char* gc_last_error(void) { return g_err; }
 #define GC_STR(x) GC_STR2(x)
 const char* gc_build_info(void) {
   return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;tiers=bf16(Bfloat16Cast);"
-         "layouts=chunked(f32)|half(f16x3: 2wg/cu,persistent,chain)|half+helpers(8 waves,1wg/cu);ring=4x16k"
+         "layouts=chunked(f32)|half(f16x3: 2wg/cu,persistent,chain)|half+helpers(8 waves,1wg/cu)|half+wide(8 multiplying waves,128 rows/ring);ring=4x16k"
          ";helpers_default=" GC_STR(GC_HELPERS_DEFAULT)
 #ifdef GC_SRC_HASH
          ";src=" GC_SRC_HASH

@@ -111,6 +111,8 @@ class StepEngine(launch.LaunchBase):
     # (0 = never; DESIGN.md section 9.7: the grid-sized node launches are 3-5 % faster in it, profiles/r04_s7_*).
     # The plan applies the same default; the attribute lets a caller (smoke(), tests) change it per engine.
     self.helpers_min_rows = int(os.environ.get("GCAST_HELPERS_MIN_ROWS", DEFAULT_HELPERS_MIN_ROWS))
+    self.wide_min_rows = None      # (None: the plan's choice.  An int: two-pass MLP launches without gather / segment-sum
+    #                                 from that many rows on run in the wide form -- smoke(), tests)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     self.c_in, self.c_out, self.num_steps = c_in, c_out, num_steps
     if c_out > 240:
@@ -190,14 +192,22 @@ class StepEngine(launch.LaunchBase):
       break
     self._cap = cap
     ops = (nat.Op * n.value).from_buffer(arr)       # (the first n entries; shares `arr`'s memory and keeps it alive)
-    # the engine-level knob on top of the plan's default: which launches take the eight-wave helper form
-    for k in range(n.value):
-      m = ops[k].mlp
-      if (ops[k].kind == nat.OP_ROWMLP and m.layout == nat.LAYOUT_HALF and m.prec == nat.PREC_F16X3
-          and not m.g0 and not m.seg):
-        m.flags &= ~nat.WG_HELPERS
-        if self.helpers_min_rows and m.n_rows >= self.helpers_min_rows:
-          m.flags |= nat.WG_HELPERS
+    # the engine-level knob on top of the plan's default (which marks the big node-side launches GC_WG_WIDE, or
+    # GC_WG_HELPERS where the wide form does not apply): set to something else than the default, it puts every launch
+    # without gather / segment-sum from that many rows on into the eight-wave HELPER form (smoke(), tests)
+    # -- or, with `wide_min_rows` set, into the WIDE form where the launch has the shape for it.
+    if (self.wide_min_rows is not None
+        or self.helpers_min_rows != int(os.environ.get("GCAST_HELPERS_MIN_ROWS", DEFAULT_HELPERS_MIN_ROWS))):
+      for k in range(n.value):
+        m = ops[k].mlp
+        if (ops[k].kind == nat.OP_ROWMLP and m.layout == nat.LAYOUT_HALF and m.prec == nat.PREC_F16X3
+            and not m.g0 and not m.seg):
+          m.flags &= ~(nat.WG_HELPERS | nat.WG_WIDE)
+          if (self.wide_min_rows is not None and m.n_rows >= self.wide_min_rows and m.mode == nat.MODE_MLP_LN
+              and m.k0 + m.k1 > 0):
+            m.flags |= nat.WG_WIDE
+          elif self.helpers_min_rows and m.n_rows >= self.helpers_min_rows:
+            m.flags |= nat.WG_HELPERS
     return ops, y
 
   def _clear_tile_queue(self):

@@ -110,6 +110,12 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /
                                   * waves, four waves that stage the weight ring for them (csrc/rowmlp_half.inc:
                                   * rowmlp16d_kernel) -- instead of two four-wave workgroups.  Bit-identical results. */
 #define GC_WG_NO_HELPERS 64      /* ... or pin the four-wave form (neither flag: the build's default, GC_HELPERS_DEFAULT) */
+#define GC_WG_WIDE 256           /* GC_LAYOUT_HALF, GC_MODE_MLP_LN launches without a segment-sum: ONE workgroup of eight
+                                  * MULTIPLYING waves per CU -- 128 rows against one weight ring, half the L2 -> LDS
+                                  * stream per row (csrc/rowmlp_half.inc: rowmlp16w_kernel).  Same bits.  Ignored where
+                                  * the launch has a segment-sum or is not a two-pass GC_MODE_MLP_LN launch. */
+#define GC_WIDE_MIN_ROWS 262144   /* the plan asks for GC_WG_WIDE from this many rows on (>= 8 rounds of 256 128-row tiles:
+                                  * below, the doubled tail costs more than the shared ring saves) */
 #define GC_TILE_QUEUE_ANY 128    /* gc_rowmlp_desc.tile_queue: hand the tiles out dynamically whenever the launch has more
                                   * tiles than workgroups (default: only from GC_TILE_QUEUE_MIN_ROUNDS tiles per
                                   * workgroup on -- below that the static walk places the few second-round tiles on
@@ -119,8 +125,10 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /
 #ifndef GC_HELPERS_DEFAULT
 #define GC_HELPERS_DEFAULT 0
 #endif
-#define GC_HELPERS_MIN_ROWS_DEFAULT 65536   /* the plan API / engine.StepEngine ask for GC_WG_HELPERS on launches without
-                                             * gather / segment-sum from this many rows on (0: never) */
+#define GC_HELPERS_MIN_ROWS_DEFAULT 65536   /* the plan API asks for ONE eight-wave workgroup per CU on launches without
+                                             * gather / segment-sum from this many rows on (0: never): GC_WG_WIDE where the
+                                             * launch is a two-pass GC_MODE_MLP_LN launch of >= GC_WIDE_MIN_ROWS rows,
+                                             * GC_WG_HELPERS elsewhere (and everywhere with GCAST_WIDE=0) */
 /* GC_LAYOUT_HALF: wave issue priority by phase (s_setprio; round 5).  Two waves share a SIMD -- the two workgroups of
  * a CU, or a multiplying and a staging wave of the eight-wave form -- and the scheduler arbitrates their VALU / MFMA
  * issue by priority, then age (MI355X_MICROARCH.md "Two waves per SIMD").  Three 2-bit fields: the priority of a wave

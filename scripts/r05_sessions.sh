@@ -189,5 +189,28 @@ PY
     unset GCAST_HELPERS_EDGE
     find "$OUT" -type f -size +8M -delete
     ;;
+  s17)
+    # Round-5 session 17: the WIDE form (rowmlp16w_kernel: eight multiplying waves per CU on one weight ring, GC_WG_WIDE /
+    # GCAST_WIDE=1 for the launches the plan marks GC_WG_HELPERS) -- bit-identity per launch, then the step A/B.
+    timeout 500 python -m pytest tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=120 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -5 "$OUT/pytest.log" | cut -c1-300
+    gate "$OUT/pytest.log" "per-launch suite with the wide form"
+    bash scripts/session.sh bench-ab r05_s17 "" "GCAST_WIDE=1" "" "GCAST_WIDE=1"
+    GCAST_WIDE=1 timeout 600 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py -m gpu -q -x --timeout=300 > "$OUT/pytest_step_wide.log" 2>&1; echo "pytest step (GCAST_WIDE=1) rc=$?"; tail -2 "$OUT/pytest_step_wide.log" | cut -c1-300
+    ;;
+  s18)
+    # Round-5 session 18: the wide form as the plan's DEFAULT for the big node-side launches -- gate (smoke, per-launch,
+    # step and plan suites), the step against GCAST_WIDE=0, the 1 deg step with the row threshold lowered to its
+    # 65,160-row grid launches, the emulated 8-way partition against GCAST_WIDE=0.
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -4
+    timeout 600 python -m pytest tests/test_rowmlp_gpu.py tests/test_step_gpu.py tests/test_plan_gpu.py -m gpu -q -x --timeout=300 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest.log" | cut -c1-300
+    gate "$OUT/pytest.log" "suites with the wide default"
+    bash scripts/session.sh bench-ab r05_s18 "" "GCAST_WIDE=0" "" "GCAST_WIDE=0"
+    bash scripts/session.sh bench-ab r05_s18_1deg --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check --rollout-steps 0 --config 1deg_13L_M5 -- "" "GCAST_HELPERS_MIN_ROWS=32768" "" "GCAST_HELPERS_MIN_ROWS=32768" "GCAST_HELPERS_MIN_ROWS=32768 GCAST_WIDE=0"
+    for E in default 0; do
+      if [ "$E" = default ]; then unset GCAST_WIDE; else export GCAST_WIDE=$E; fi
+      timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8_wide_$E.json" 2>&1 | grep -v amdgpu | tail -1 | cut -c1-330
+    done
+    unset GCAST_WIDE
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

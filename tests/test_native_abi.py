@@ -125,6 +125,9 @@ def test_build_checks_the_register_budget_of_the_hot_kernels():
             "x.inc:1:1: remark: Function Name: _ZN12_GLOBAL__N_116rowmlp16d_kernelILi1ELi0EEEv14gc_rowmlp_desc [-R]\n"
             "x.inc:1:1: remark:     ScratchSize [bytes/lane]: 116 [-R]\n"
             "x.inc:1:1: remark:     Occupancy [waves/SIMD]: 2 [-R]\n"
+            "x.inc:1:1: remark: Function Name: _ZN12_GLOBAL__N_116rowmlp16w_kernelILi1EEEv14gc_rowmlp_desc [-R]\n"
+            "x.inc:1:1: remark:     ScratchSize [bytes/lane]: 112 [-R]\n"
+            "x.inc:1:1: remark:     Occupancy [waves/SIMD]: 2 [-R]\n"
             "x.inc:1:1: remark: Function Name: _ZN12_GLOBAL__N_115rowmlpbf_kernelILb0ELi4EEEv14gc_rowmlp_desc [-R]\n"
             "x.inc:1:1: remark:     ScratchSize [bytes/lane]: 244 [-R]\n"
             "x.inc:1:1: remark:     Occupancy [waves/SIMD]: 2 [-R]\n")

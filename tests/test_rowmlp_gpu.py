@@ -568,6 +568,12 @@ def test_half_reads_unaligned_rows_in_place(dev):
   z = np.concatenate([x[:, b], st], axis=1).astype(np.float64) @ w.astype(np.float64) + p["b1"]
   want = _ln(ognn.swish(z) @ p["w2"].astype(np.float64) + p["b2"], p["scale"], p["offset"])
   assert_close(out.cpu().numpy(), want, "in-place unaligned rows + tail")
+  # round 5: the same launch (the grid embedder's shape: 4-byte aligned external rows, K = 448 + 32) in the wide form
+  first = out.clone()
+  out.fill_(float("nan"))
+  d.flags = nat.WG_WIDE
+  run(d)
+  assert torch.equal(first, out)
 
 
 def test_half_persistent_loop_revisits_scratch_slots(dev):
@@ -602,7 +608,9 @@ def test_half_persistent_loop_revisits_scratch_slots(dev):
   assert torch.equal(first[0], out) and torch.equal(first[1], y)
   # round 4: the same launch as ONE eight-wave workgroup per CU (four multiplying + four staging waves,
   # GC_WG_HELPERS) and with the XCD-contiguous tile map (GC_TILE_XCD) -- speed choices: the same bits
-  for flags in (nat.WG_HELPERS, nat.TILE_MAP_XCD, nat.WG_HELPERS | nat.TILE_MAP_XCD):
+  # round 5: ... and as ONE workgroup of eight MULTIPLYING waves per CU on one weight ring (GC_WG_WIDE: 128-row tiles,
+  # two scratch slots per workgroup; 301 tiles on 256 workgroups, the last one half empty)
+  for flags in (nat.WG_HELPERS, nat.TILE_MAP_XCD, nat.WG_HELPERS | nat.TILE_MAP_XCD, nat.WG_WIDE):
     out.zero_(); y.zero_()
     d.flags = flags
     run(d)
@@ -612,7 +620,7 @@ def test_half_persistent_loop_revisits_scratch_slots(dev):
   # two words zero, so the next launch (and the next form) can reuse them
   queue = torch.zeros((2,), dtype=torch.int32, device=dev)
   d.tile_queue = queue.data_ptr()
-  for flags in (nat.WG_NO_HELPERS, nat.WG_HELPERS, nat.WG_NO_HELPERS):
+  for flags in (nat.WG_NO_HELPERS, nat.WG_HELPERS, nat.WG_WIDE, nat.WG_NO_HELPERS):
     out.zero_(); y.zero_()
     d.flags = flags | nat.TILE_QUEUE_ANY      # (by default only launches of >= 4 tiles per workgroup use the queue)
     run(d)
@@ -685,6 +693,14 @@ def test_small_launches_give_the_same_bits_in_both_kernel_forms(dev):
   _chain_stage(d, 0, tws, nat.CHAIN_ROWS, out=o_s, ldo=D)
   _chain_stage(d, 1, twr, nat.CHAIN_ROWS, out=o_r, ldo=D)
   run_all_forms(d, [o, o_s, o_r])
+  # ... and in the wide form (GC_WG_WIDE; round 5): two 128-row tiles, the second one's waves 4.3 .. 7 beyond the rows
+  want = [x.clone() for x in (o, o_s, o_r)]
+  for x in (o, o_s, o_r):
+    x.fill_(float("nan"))
+  d.flags = nat.WG_WIDE
+  run(d)
+  for a, b in zip(want, (o, o_s, o_r)):
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("n_recv", [300, 9000])

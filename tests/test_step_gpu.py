@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+from graphcast_amd import _native as nat            # noqa: E402
 from graphcast_amd import graphcast as gc          # noqa: E402
 from oracle import graphcast as ogc                # noqa: E402
 from oracle import params as oparams               # noqa: E402
@@ -75,6 +76,32 @@ def test_step_is_deterministic_and_batch_independent(small):
   assert torch.equal(y1, y2)                    # bitwise: no float atomics
   y_single = m.forward_grid_node_features(x[:, 1:2].contiguous())
   assert torch.equal(y_single[:, 0], y1[:, 1])  # batch is a pure broadcast axis (graphcast.py:726-730)
+
+
+def test_step_gives_the_same_bits_in_the_one_workgroup_per_cu_forms(small):
+  """The big node-side launches of the headline size (grid embedder, grid-node update, decoder node update + output
+  MLP: no gather, no segment-sum) run as ONE eight-wave workgroup per CU -- round 5: in the WIDE form (eight multiplying
+  waves, 128 rows against one weight ring; csrc/rowmlp_half.inc: rowmlp16w_kernel), round 4: the helper form (four
+  multiplying + four staging waves).  Here, where no launch reaches the row threshold, the engine knobs put EVERY such
+  launch into either form: the whole step's output is bitwise the four-wave form's, batch 1 and 2."""
+  if small["precision"] != "f16x3":
+    pytest.skip("the eight-wave forms are GC_PREC_F16X3 kernels")
+  rng = np.random.default_rng(21)
+  n = small["graphs"]["n_grid"]
+  x = torch.from_numpy(rng.standard_normal((n, 2, small["c_in"])).astype(np.float32)).to("cuda:0")
+  want = small["model"].forward_grid_node_features(x).clone()
+  cfg = small["model"]._model_config
+  lat = np.arange(-90, 90 + cfg.resolution / 2, cfg.resolution)
+  lon = np.arange(0, 360, cfg.resolution)
+  for knob in ("wide_min_rows", "helpers_min_rows"):
+    m = gc.GraphCast(cfg, gc.TASK_13, params=small["params"], precision="f16x3").init_from_coordinates(lat, lon)
+    setattr(m._get_engine(small["c_in"]), knob, 1)            # (read when the launch program is recorded: the first step)
+    y = m.forward_grid_node_features(x)
+    torch.cuda.synchronize()
+    ops, _ = m._engine.bind(x)
+    marked = [ops[k].mlp.flags & (nat.WG_WIDE | nat.WG_HELPERS) for k in range(len(ops)) if ops[k].kind == nat.OP_ROWMLP]
+    assert sum(f == (nat.WG_WIDE if knob == "wide_min_rows" else nat.WG_HELPERS) for f in marked) >= 3, (knob, marked)
+    assert torch.equal(y, want), knob
 
 
 def test_missing_params_and_bad_shapes_raise(small):
