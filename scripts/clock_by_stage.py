@@ -28,7 +28,7 @@ def main():
     with open(f, newline="") as fh:
       for r in csv.DictReader(fh):
         k = r["Kernel_Name"]
-        if ("rowmlp16h_kernel" in k or "rowmlp16d_kernel" in k) and "<0" not in k and r["Counter_Name"] == "SQ_WAVE_CYCLES":
+        if ("rowmlp16h_kernel" in k or "rowmlp16d_kernel" in k or "rowmlp16w_kernel" in k) and "<0" not in k and r["Counter_Name"] == "SQ_WAVE_CYCLES":
           i = int(r["Dispatch_Id"])
           cyc[i] = cyc.get(i, 0.0) + float(r["Counter_Value"])
           grid[i] = int(r["Grid_Size"]) // 64          # waves of the launch

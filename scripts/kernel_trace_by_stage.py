@@ -28,7 +28,7 @@ def main():
         if kernel in r["Kernel_Name"] and "<0" not in r["Kernel_Name"] and "ILi0E" not in r["Kernel_Name"]:
           rows.append((int(r["Dispatch_Id"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                        r["VGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"], r["Grid_Size_X"],
-                       "rowmlp16d" if "rowmlp16d" in r["Kernel_Name"] else "rowmlp16h"))
+                       "rowmlp16d" if "rowmlp16d" in r["Kernel_Name"] else "rowmlp16w" if "rowmlp16w" in r["Kernel_Name"] else "rowmlp16h"))
   rows.sort()
   n = len(STAGES)
   steps = len(rows) // n

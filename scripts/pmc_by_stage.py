@@ -29,7 +29,7 @@ def rowmlp_values(root, kernel_sub):
   for f in files:
     with open(f, newline="") as fh:
       for r in csv.DictReader(fh):
-        # (rowmlp16h_kernel / rowmlp16d_kernel: the four-wave and the helper-wave form of the same launch)
+        # (rowmlp16h_kernel / rowmlp16d_kernel / rowmlp16w_kernel: the four-wave, helper-wave and wide form of the same launch)
         if any(k in r["Kernel_Name"] for k in kernel_sub) and "<0" not in r["Kernel_Name"]:
           rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
   rows.sort()
@@ -56,7 +56,7 @@ def algorithmic(elem):
 def main():
   fetch_dir, write_dir = sys.argv[1], sys.argv[2]
   elem = int(sys.argv[sys.argv.index("--elem") + 1]) if "--elem" in sys.argv else 4
-  kernel = ("rowmlpbf_kernel",) if elem == 2 else ("rowmlp16h_kernel", "rowmlp16d_kernel")
+  kernel = ("rowmlpbf_kernel",) if elem == 2 else ("rowmlp16h_kernel", "rowmlp16d_kernel", "rowmlp16w_kernel")
   f, w = rowmlp_values(fetch_dir, kernel), rowmlp_values(write_dir, kernel)
   n = len(STAGES)
   if len(f) < n or len(w) < n:

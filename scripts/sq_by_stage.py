@@ -38,7 +38,7 @@ def main():
       with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
           k = r["Kernel_Name"]
-          if ("rowmlp16h_kernel" in k or "rowmlp16d_kernel" in k) and "<0" not in k:
+          if ("rowmlp16h_kernel" in k or "rowmlp16d_kernel" in k or "rowmlp16w_kernel" in k) and "<0" not in k:
             d = per[r["Counter_Name"]]
             d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
   out = {}
