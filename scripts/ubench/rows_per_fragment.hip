@@ -10,6 +10,8 @@
 //   2  rows32    one 4-wave workgroup per CU,  32 rows per wave (2 B sets)   DMA 1x  LDS reads 1x   (needs ~384 registers in the
 //                                                                                                    real kernel: one wave per SIMD)
 //   3  m32       as 2 with v_mfma_f32_32x32x16_f16: half the register-file operand reads per MAC as well
+//   4  helper    one 8-wave workgroup per CU: 4 multiplying + 4 weight-staging waves     DMA 2x  LDS reads 2x   (round 4's form
+//                                                                                       of the big node-side launches)
 //
 // Every variant runs ~2 s on all 256 CUs with random f16 operands while the host polls `amd-smi` for socket power and
 // shader clock; the figure of merit is wall time for the same MFMA work (= energy at the power limit).
@@ -132,14 +134,34 @@ __device__ __forceinline__ void quarter32(f16v (&acc)[8], int nb0, const u4* wb,
 
 // WAVES waves share one ring (each stages 16 / WAVES pieces of every quarter itself: the shipped structure);
 // RS = B operand sets per wave (16 rows each); M32: the 32-row form with 32x32x16 MFMAs.
-template <int WAVES, int RS, int M32, int WGS_PER_CU>
-__global__ __launch_bounds__(64 * WAVES, WGS_PER_CU) void rpf(const float* __restrict__ w, f4* out, int n_quarters) {
+// HELP: waves 0-3 multiply (16 rows each, no DMA), waves 4-7 stage the whole ring for them (4 pieces per wave and
+// quarter) -- the shipped rowmlp16d_kernel's split; 96 MFMAs per CU and quarter, so the host runs it over twice the quarters.
+template <int WAVES, int RS, int M32, int WGS_PER_CU, int HELP = 0>
+__global__ __launch_bounds__(64 * (HELP ? 8 : WAVES), HELP ? 2 : WGS_PER_CU) void rpf(const float* __restrict__ w, f4* out, int n_quarters) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int PPW = 16 / WAVES;
+  constexpr int PPW = HELP ? 0 : 16 / WAVES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   auto src = [&](int q) { return w + (size_t)(q % kStream) * kQFloats; };
   auto buf = [&](int q) { return smem + (q % kRing) * kQFloats; };
+  if constexpr (HELP != 0) {
+    if (wave >= 4) {
+      const int hw = wave & 3;
+      for (int q = 0; q < kRing - 1; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) piece(src(q), buf(q), 4 * hw + p, lane);
+#pragma unroll 1
+      for (int q = 0; q < n_quarters; ++q) {
+        if (q < kRing) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRing - 2) * 4) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) piece(src(q + kRing - 1), buf(q + kRing - 1), 4 * hw + p, lane);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+  }
   for (int q = 0; q < kRing - 1; ++q)
 #pragma unroll
     for (int p = 0; p < PPW; ++p) piece(src(q), buf(q), PPW * wave + p, lane);
@@ -150,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES, WGS_PER_CU) void rpf(const float* __res
     bl[r] = reinterpret_cast<const u4*>(w)[lane + 64 * ((wave + 3 * r) & 7) + 512];
   }
   u4 fh[NG], fl[NG];
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRing - 2) * PPW) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRing - 2) * PPW) : "memory");       // (also this wave's B operand loads)
   asm volatile("s_barrier" ::: "memory");
   {
     const u4* wb = reinterpret_cast<const u4*>(buf(0)) + lane;
@@ -245,13 +267,15 @@ static double median(std::vector<double> v) {
   return v[v.size() / 2];
 }
 
-template <int WAVES, int RS, int M32, int WGS_PER_CU>
-void run(const char* name, const float* w, f4* out, int nq) {
+template <int WAVES, int RS, int M32, int WGS_PER_CU, int HELP = 0>
+void run(const char* name, const float* w, f4* out, int nq_in) {
+  const int nq = HELP ? 2 * (nq_in - 1) + 1 : nq_in;          // (the helper form multiplies with four waves per CU: twice the quarters)
   const size_t lds = WGS_PER_CU == 2 ? kRing * kQFloats * sizeof(float) : 96 * 1024;   // (96 KiB: ONE workgroup per CU)
-  auto fn = rpf<WAVES, RS, M32, WGS_PER_CU>;
+  auto fn = rpf<WAVES, RS, M32, WGS_PER_CU, HELP>;
+  constexpr int kThreads = 64 * (HELP ? 8 : WAVES);
   hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int blocks = 256 * WGS_PER_CU;
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * WAVES), lds, 0, w, out, 65);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(kThreads), lds, 0, w, out, 65);
   {
     const hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("%s: launch failed: %s\n", name, hipGetErrorString(e)); exit(1); }
@@ -261,7 +285,7 @@ void run(const char* name, const float* w, f4* out, int nq) {
   std::vector<double> pw, ck;
   std::atomic<bool> stop{false};
   hipEventRecord(e0);
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * WAVES), lds, 0, w, out, nq);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(kThreads), lds, 0, w, out, nq);
   hipEventRecord(e1);
   std::thread poll([&] {
     std::this_thread::sleep_for(std::chrono::milliseconds(400));     // (the governor settles within ~0.3 s)
@@ -276,8 +300,8 @@ void run(const char* name, const float* w, f4* out, int nq) {
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   // MFMA pipe cycles per SIMD: every variant issues 48 x 16 cycles per (quarter pair of the pair form | quarter of the others)
-  const double mfma_cycles = (double)(nq - 1) * 768.0;
-  const double macs = (double)(nq - 1) * 192.0 * 8192.0 * 256.0;       // per launch, all CUs
+  const double mfma_cycles = (double)(nq_in - 1) * 768.0;
+  const double macs = (double)(nq_in - 1) * 192.0 * 8192.0 * 256.0;    // per launch, all CUs
   const double mhz = median(ck);
   printf("{\"variant\": \"%s\", \"ms\": %.2f, \"mfma_tflops\": %.1f, \"power_w_median\": %.0f, \"sclk_mhz_median\": %.0f, \"samples\": %zu, "
          "\"mfma_pipe_busy_at_that_clock\": %.3f, \"joule_per_tmac\": %.3f}\n",
@@ -311,7 +335,8 @@ int main(int argc, char** argv) {
     case 1: run<8, 1, 0, 1>("wide: 8 waves x 16 rows, one ring (DMA 1x, LDS reads 2x)", w, out, nq); break;
     case 2: run<4, 2, 0, 1>("rows32: 4 waves x 32 rows (DMA 1x, LDS reads 1x)", w, out, nq); break;
     case 3: run<4, 2, 1, 1>("m32: 4 waves x 32 rows, 32x32x16 MFMAs (DMA 1x, LDS reads 1x, operand reads 1/2)", w, out, nq); break;
-    default: printf("usage: rows_per_fragment <variant 0..3> [quarters]\n");
+    case 4: run<4, 1, 0, 1, 1>("helper: 4 multiplying + 4 staging waves x 16 rows (DMA 2x, LDS reads 2x)", w, out, nq); break;
+    default: printf("usage: rows_per_fragment <variant 0..4> [quarters]\n");
   }
   return 0;
 }
