@@ -143,3 +143,18 @@ def test_build_checks_the_register_budget_of_the_hot_kernels():
     nat.check_resources("x.inc:1:1: remark: Function Name: some_other_kernel [-R]\n")
   with pytest.raises(RuntimeError, match="no kernel-resource-usage remark"):
     nat.check_resources("")
+
+
+@pytest.mark.parametrize("name", ["rows_per_fragment", "gh_skeleton", "mfma_issue"])
+def test_micro_benchmarks_cross_compile_for_gfx950(name, tmp_path):
+  """scripts/ubench/*.hip -- the skeletons DESIGN.md section 9 prices kernel structures with before they are built --
+  stay compilable for gfx950 (no GPU needed: hipcc cross-compiles)."""
+  import shutil
+  import subprocess
+  hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+  if not os.path.exists(hipcc):
+    pytest.skip("no hipcc in this environment")
+  src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "ubench", name + ".hip")
+  r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-c", src, "-o", str(tmp_path / (name + ".o"))],
+                     capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-2000:]
