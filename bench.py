@@ -430,12 +430,15 @@ def main():
         "output_finite": finite,
         "formulation": (("half-N kernels, two persistent four-wave workgroups per CU, chained layers"
                          + (f"; launches without gather / segment-sum from {engine.helpers_min_rows} rows on as ONE eight-wave "
-                            + ("workgroup per CU (four multiplying + four weight-staging waves)" if os.environ.get("GCAST_WIDE") == "0"
+                            + ("workgroup per CU (four multiplying + four weight-staging waves)" if not nat.get_tuning().wide
                                else "workgroup per CU (the wide form: eight multiplying waves on one weight ring)")
                             if getattr(engine, "helpers_min_rows", 0) else "")) if getattr(engine, "fuse", False)
                         else "half-N kernels, two persistent workgroups per CU" if getattr(engine, "half", False)
                         else "chunked, one workgroup per CU"),
         "build": nat.lib().gc_build_info().decode(),
+        # the library's ONE tuning surface (include/gcast.h: gc_tuning) as this process ran with it -- every speed-only
+        # A/B switch, whatever set it (the GCAST_* variables only initialise it)
+        "tuning": nat.tuning_string(),
     }
     if args.gpus == 1 and args.rollout_steps > 0 and args.config == "0.25deg_37L_M6":
       line["rollout"] = rollout_extra(model, task, lat, lon, args.rollout_steps)
@@ -724,7 +727,7 @@ def partition_main(args, rank, world, device, distributed):
         "roofline": roofline,
         "cpu_baseline": cpu,
         "precision": precision, "output_finite": finite,
-        "build": nat.lib().gc_build_info().decode()})
+        "build": nat.lib().gc_build_info().decode(), "tuning": nat.tuning_string()})
   dist.destroy_process_group()
   if rank == 0:
     emit_line(line)

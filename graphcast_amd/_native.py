@@ -25,7 +25,8 @@ LATENT = 512
 TILE_MAP_XCD = 16                                 # GC_TILE_XCD
 TILE_QUEUE_ANY = 128                              # GC_TILE_QUEUE_ANY: the dynamic tile queue whenever a launch has a second round
 WG_HELPERS, WG_NO_HELPERS = 32, 64                # GC_WG_HELPERS / GC_WG_NO_HELPERS (eight-wave form of a GC_LAYOUT_HALF launch)
-WG_WIDE = 256                                     # GC_WG_WIDE (eight MULTIPLYING waves per CU on one weight ring; no segment-sum)
+WG_WIDE = 256                                     # GC_WG_WIDE (eight MULTIPLYING waves per CU on one weight ring; round 6: segment-sum / one-pass launches too)
+WIDE_EDGES_DEFAULT = 0                            # GC_WIDE_EDGES_DEFAULT (gc_tuning.wide_edges of a process without GCAST_WIDE_EDGES)
 TILE_ROWS = 64
 K_CHUNK = 32
 SCRATCH_SLOTS = 512                               # GC_SCRATCH_SLOTS: persistent workgroups of a GC_LAYOUT_HALF launch
@@ -117,7 +118,19 @@ class AdvanceDesc(ctypes.Structure):
   ]
 
 
-EXPORTS = ("gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_plan_check_range", "gc_plan_destroy",
+class Tuning(ctypes.Structure):
+  """struct gc_tuning (include/gcast.h): the library's ONE tuning surface -- speed-only A/B switches; the GCAST_*
+  environment variables only initialise the process default."""
+  _fields_ = [(name, ctypes.c_int) for name in (
+      "grid_cap", "tile_map_xcd", "prio_set", "prio_gemm", "prio_other", "prio_stage", "helpers", "helpers_small",
+      "helpers_edge", "helper_store", "helpers_min_rows", "wide", "wide_edges", "bf16_rows", "tile_queue", "fuse",
+      "onepass")] + [("reserved", ctypes.c_int * 8)]
+
+  def as_dict(self):
+    return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+EXPORTS = ("gc_get_tuning", "gc_set_tuning", "gc_plan_get_tuning", "gc_tuning_string", "gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_plan_check_range", "gc_plan_destroy",
            "gc_plan_program", "gc_plan_tensor",
            "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_add_rows", "gc_prep_grid_input", "gc_prep_grid_tail",
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
@@ -310,11 +323,18 @@ def lib():
     l.gc_host_pack_edges.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_int] + [_fp] * 5 + [
         ctypes.POINTER(ctypes.c_int), _fp, ctypes.POINTER(ctypes.c_int)]
     l.gc_host_pack_edges.restype = ctypes.c_int
+    l.gc_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
+    l.gc_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
+    l.gc_plan_get_tuning.argtypes = [ctypes.c_void_p, ctypes.POINTER(Tuning)]
+    l.gc_get_tuning.restype = l.gc_set_tuning.restype = l.gc_plan_get_tuning.restype = ctypes.c_int
+    l.gc_tuning_string.argtypes = [ctypes.POINTER(Tuning)]
+    l.gc_tuning_string.restype = ctypes.c_char_p
     l.gc_last_error.restype = ctypes.c_char_p
     l.gc_abi_sizeof.argtypes = [ctypes.c_int]
     l.gc_abi_sizeof.restype = ctypes.c_size_t
     if (l.gc_abi_sizeof(0) != ctypes.sizeof(RowMlpDesc) or l.gc_abi_sizeof(1) != ctypes.sizeof(Op)
-        or l.gc_abi_sizeof(2) != ctypes.sizeof(AdvanceDesc) or l.gc_abi_sizeof(3) != ctypes.sizeof(ModelDesc)):
+        or l.gc_abi_sizeof(2) != ctypes.sizeof(AdvanceDesc) or l.gc_abi_sizeof(3) != ctypes.sizeof(ModelDesc)
+        or l.gc_abi_sizeof(4) != ctypes.sizeof(Tuning)):
       raise RuntimeError("ctypes struct layout does not match include/gcast.h "
                          f"({l.gc_abi_sizeof(0)}/{ctypes.sizeof(RowMlpDesc)}, "
                          f"{l.gc_abi_sizeof(1)}/{ctypes.sizeof(Op)}); rebuild the library")
@@ -341,6 +361,30 @@ EINVAL, ELAUNCH, ERANGE = -1, -2, -3
 def check(rc, what):
   if rc != 0:
     raise GcastError(f"{what} failed ({rc}): {lib().gc_last_error().decode()}")
+
+
+def get_tuning() -> Tuning:
+  """The process default of the library's tuning (gc_get_tuning)."""
+  t = Tuning()
+  check(lib().gc_get_tuning(ctypes.byref(t)), "gc_get_tuning")
+  return t
+
+
+def set_tuning(t: Tuning = None, **fields) -> Tuning:
+  """gc_set_tuning: replaces the process default by `t` (default: the current one) with `fields` overridden; returns
+  the PREVIOUS tuning (hand it back to restore).  Plans created afterwards snapshot the new values."""
+  prev = get_tuning()
+  new = Tuning.from_buffer_copy(bytes(t if t is not None else prev))
+  for k, v in fields.items():
+    if k not in new.as_dict():
+      raise KeyError(f"gc_tuning has no field {k!r}")
+    setattr(new, k, int(v))
+  check(lib().gc_set_tuning(ctypes.byref(new)), "gc_set_tuning")
+  return prev
+
+
+def tuning_string(t: Tuning = None) -> str:
+  return lib().gc_tuning_string(ctypes.byref(t) if t is not None else None).decode()
 
 
 def ptr(t):

@@ -752,44 +752,62 @@ int launch_rowmlp(const gc_rowmlp_desc& d, hipStream_t s) {
 
 bool g_h_attr_set[3][4] = {};
 
-// A/B switches of the persistent GC_LAYOUT_HALF launches, read once per process (measurement runs of bench.py):
-// GCAST_GRID_CAP=<n <= GC_SCRATCH_SLOTS> workgroups per launch (256 = one per CU), GCAST_TILE_MAP=xcd|rr the
-// tile -> workgroup map (GC_TILE_XCD; a launch can also ask for it in gc_rowmlp_desc.flags).
-int half_grid_cap() {
-  static const int v = [] {
-    const char* e = std::getenv("GCAST_GRID_CAP");
-    const int n = e ? std::atoi(e) : 0;
-    return n > 0 && n <= GC_SCRATCH_SLOTS ? n : GC_SCRATCH_SLOTS;
-  }();
-  return v;
+// ONE tuning surface (include/gcast.h: gc_tuning).  The GCAST_* environment variables initialise the process default
+// the first time it is needed and are never read again; gc_set_tuning replaces it; gc_plan_create snapshots it.  No
+// launch function below calls getenv.
+gc_tuning tuning_from_env() {
+  gc_tuning t;
+  std::memset(&t, 0, sizeof(t));
+  auto env_int = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+  const int cap = env_int("GCAST_GRID_CAP", 0);
+  t.grid_cap = cap > 0 && cap <= GC_SCRATCH_SLOTS ? cap : GC_SCRATCH_SLOTS;
+  { const char* e = std::getenv("GCAST_TILE_MAP"); t.tile_map_xcd = e && std::strcmp(e, "xcd") == 0; }
+  t.prio_gemm = GC_PRIO_GEMM_DEFAULT; t.prio_other = GC_PRIO_OTHER_DEFAULT; t.prio_stage = GC_PRIO_STAGE_DEFAULT;
+  if (const char* e = std::getenv("GCAST_PRIO")) {
+    t.prio_set = 1;
+    t.prio_gemm = t.prio_other = t.prio_stage = 0;
+    std::sscanf(e, "%d,%d,%d", &t.prio_gemm, &t.prio_other, &t.prio_stage);
+    t.prio_gemm &= 3; t.prio_other &= 3; t.prio_stage &= 3;
+  }
+  t.helpers = std::getenv("GCAST_HELPERS") ? (env_int("GCAST_HELPERS", 0) != 0) : (GC_HELPERS_DEFAULT ? 1 : -1);
+  t.helpers_small = env_int("GCAST_HELPERS_SMALL", 1) != 0;
+  t.helpers_edge = std::getenv("GCAST_HELPERS_EDGE") ? (env_int("GCAST_HELPERS_EDGE", 0) != 0 ? 2 : 0) : 1;
+  { const int v = env_int("GCAST_HELPER_STORE", 2); t.helper_store = v < 0 ? 0 : v > 2 ? 2 : v; }
+  { const int v = env_int("GCAST_HELPERS_MIN_ROWS", GC_HELPERS_MIN_ROWS_DEFAULT); t.helpers_min_rows = v < 0 ? 0 : v; }
+  t.wide = env_int("GCAST_WIDE", 1) != 0;
+  t.wide_edges = env_int("GCAST_WIDE_EDGES", GC_WIDE_EDGES_DEFAULT) & 3;
+  { const int v = env_int("GCAST_BF16_ROWS", 0); t.bf16_rows = (v == 64 || v == 128) ? v : 0; }
+  t.tile_queue = env_int("GCAST_TILE_QUEUE", 1) != 0;
+  { const char* e = std::getenv("GCAST_FUSE"); t.fuse = !(e && std::strcmp(e, "0") == 0); }
+  { const char* e = std::getenv("GCAST_ONEPASS"); t.onepass = !(e && std::strcmp(e, "0") == 0); }
+  return t;
 }
-bool half_tile_xcd() {
-  static const bool v = [] {
-    const char* e = std::getenv("GCAST_TILE_MAP");
-    return e && std::strcmp(e, "xcd") == 0;
-  }();
-  return v;
+gc_tuning& tuning_mut() {
+  static gc_tuning t = tuning_from_env();
+  return t;
 }
+inline const gc_tuning& tuning() { return tuning_mut(); }
+bool tuning_valid(const gc_tuning& t) {
+  auto b = [](int v) { return v == 0 || v == 1; };
+  return t.grid_cap >= 1 && t.grid_cap <= GC_SCRATCH_SLOTS && b(t.tile_map_xcd) && b(t.prio_set) && !(t.prio_gemm & ~3) &&
+         !(t.prio_other & ~3) && !(t.prio_stage & ~3) && t.helpers >= -1 && t.helpers <= 1 && b(t.helpers_small) &&
+         t.helpers_edge >= 0 && t.helpers_edge <= 2 && t.helper_store >= 0 && t.helper_store <= 2 && t.helpers_min_rows >= 0 &&
+         b(t.wide) && !(t.wide_edges & ~3) && (t.bf16_rows == 0 || t.bf16_rows == 64 || t.bf16_rows == 128) && b(t.tile_queue) &&
+         b(t.fuse) && b(t.onepass);
+}
+int half_grid_cap() { return tuning().grid_cap; }
+bool half_tile_xcd() { return tuning().tile_map_xcd != 0; }
 
-// GCAST_PRIO="g,e,s" (read once): wave priorities of every GC_LAYOUT_HALF launch of the process -- GEMM phases, the other
-// phases, staging waves (include/gcast.h GC_PRIO); a launch that carries its own GC_PRIO bits keeps them.
-// Default (round 5, same-session A/B of the whole 0.25 deg step, profiles/r05_s2_*): GEMM phases at priority 1 in the
-// f16x3 kernels -- processor edge update 19.91 -> 19.43 ms per step, whole step 50.73 -> 50.47 ms; priorities 2 / 3 and
-// a raised priority OUTSIDE the GEMM phases measured within noise of the default, the helper-wave form and the bf16
-// tier do not react at all (their defaults stay 0).
+// Wave priorities of a GC_LAYOUT_HALF launch that does not carry its own GC_PRIO bits: GEMM phases, the other phases,
+// staging waves (include/gcast.h GC_PRIO).  Default (round 5, same-session A/B of the whole 0.25 deg step,
+// profiles/r05_s2_*): GEMM phases at priority 1 in the f16x3 kernels -- processor edge update 19.91 -> 19.43 ms per
+// step, whole step 50.73 -> 50.47 ms; priorities 2 / 3 and a raised priority OUTSIDE the GEMM phases measured within
+// noise of the default, the helper-wave form and the bf16 tier do not react at all (their defaults stay 0: the tuning's
+// three values reach the bf16 kernels only when they were given explicitly, gc_tuning.prio_set).
 int half_prio_flags(bool bf16) {
-  static const int v[2] = {[] {
-    const char* e = std::getenv("GCAST_PRIO");
-    int g = GC_PRIO_GEMM_DEFAULT, o = GC_PRIO_OTHER_DEFAULT, st = GC_PRIO_STAGE_DEFAULT;
-    if (e) std::sscanf(e, "%d,%d,%d", &g, &o, &st);
-    return GC_PRIO(g, o, st);
-  }(), [] {
-    const char* e = std::getenv("GCAST_PRIO");
-    int g = 0, o = 0, st = 0;
-    if (e) std::sscanf(e, "%d,%d,%d", &g, &o, &st);
-    return GC_PRIO(g, o, st);
-  }()};
-  return v[bf16 ? 1 : 0];
+  const gc_tuning& t = tuning();
+  if (bf16 && !t.prio_set) return GC_PRIO(0, 0, 0);
+  return GC_PRIO(t.prio_gemm, t.prio_other, t.prio_stage);
 }
 inline void apply_prio(gc_rowmlp_desc& dd, bool bf16 = false) {
   if (!((dd.flags >> GC_PRIO_SHIFT) & 63)) dd.flags |= half_prio_flags(bf16);
@@ -807,7 +825,7 @@ inline bool tile_queue_pays(const gc_rowmlp_desc& d, int tiles, int grid) {
   return d.tile_queue && (tiles >= GC_TILE_QUEUE_MIN_ROUNDS * grid || ((d.flags & GC_TILE_QUEUE_ANY) && tiles > grid));
 }
 
-template <int MODE>
+template <int MODE, int ONEPASS>
 int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s);
 
 template <int MODE, int ONEPASS = 0>
@@ -815,8 +833,14 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   // The wide form (csrc/rowmlp_half.inc: rowmlp16w_kernel; eight multiplying waves per CU on ONE weight ring): asked for
   // per launch with GC_WG_WIDE -- the plan marks the big launches without gather or segment-sum (gcast_plan.inc: op_mlp).
   // Two-pass GC_MODE_MLP_LN launches without a segment-sum only: elsewhere the flag is ignored (a speed choice).
-  if constexpr (MODE == GC_MODE_MLP_LN && ONEPASS == 0) {
-    if ((d.flags & GC_WG_WIDE) && !d.seg) return launch_rowmlp_half_w<MODE>(d, s);
+  // Round 6: the form also takes launches with a segment-sum (two 64-row sub-tiles per workgroup) and the one-pass edge
+  // updates; gc_tuning.wide_edges asks for it on edge updates of at least GC_WIDE_EDGE_MIN_TILES tiles that do not pin
+  // another form (bit 0: one-pass, bit 1: two-pass).
+  if constexpr (MODE == GC_MODE_MLP_LN) {
+    const bool wide_edge = d.seg && !(d.flags & (GC_WG_HELPERS | GC_WG_NO_HELPERS)) &&
+                           (tuning().wide_edges & (ONEPASS != 0 ? 1 : 2)) && tuning().helpers != 1 &&
+                           (d.n_rows + kHRows - 1) / kHRows >= GC_WIDE_EDGE_MIN_TILES;
+    if ((d.flags & GC_WG_WIDE) || wide_edge) return launch_rowmlp_half_w<MODE, ONEPASS>(d, s);
   }
   // Which form.  Asked for per launch (GC_WG_HELPERS / GC_WG_NO_HELPERS), or per process (GCAST_HELPERS); otherwise:
   // a launch of at most one tile per CU runs one four-wave workgroup per CU anyway -- for the node-side launches (no
@@ -825,11 +849,8 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   // launches (small grids, the 8-way partition's ranks) take it; GCAST_HELPERS_SMALL=0 switches the rule off (A/B).
   // GCAST_HELPERS=0 (the per-process "four-wave form everywhere" switch) turns it off as well; GC_WG_NO_HELPERS pins
   // the four-wave form per launch.
-  static const bool small_rule = [] {
-    const char* e = std::getenv("GCAST_HELPERS_SMALL");
-    const char* h = std::getenv("GCAST_HELPERS");
-    return (!e || std::atoi(e) != 0) && !(h && std::atoi(h) == 0);
-  }();
+  const gc_tuning& T = tuning();
+  const bool small_rule = T.helpers_small && T.helpers != 0;
   const bool small = small_rule && !d.g0 && !d.seg && (d.n_rows + kHRows - 1) / kHRows <= GC_SCRATCH_SLOTS / 2;
   // Round 5: the processor's edge update from step 1 on (two-pass, b1 + g0 + g1, segment-sum, rows stored) in the
   // eight-wave form -- its staging waves take residual + store and gather the next tile's addends (rowmlp_half.inc:
@@ -839,13 +860,8 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   // size (5,120 tiles) the part runs at its power limit -- 1367 W at 1.94 GHz, profiles/r05_s12_* -- and the launch
   // behind a faster launch slows down by what was gained (5.69 -> 6.64 ms per step; whole step 53.02 -> 53.22 ms):
   // DESIGN.md section 9.14.  Hence the rule: by default for launches of more than one and at most
-  // GC_HELPERS_EDGE_MAX_TILES tiles per ... launch; GCAST_HELPERS_EDGE=1 at every size, =0 (or GCAST_HELPERS=0) never.
-  static const int edge_rule = [] {
-    const char* e = std::getenv("GCAST_HELPERS_EDGE");
-    const char* h = std::getenv("GCAST_HELPERS");
-    if (h && std::atoi(h) == 0) return 0;
-    return e ? (std::atoi(e) != 0 ? 2 : 0) : 1;
-  }();
+  // GC_HELPERS_EDGE_MAX_TILES tiles per ... launch; gc_tuning.helpers_edge = 2 at every size, 0 (or helpers = 0) never.
+  const int edge_rule = T.helpers == 0 ? 0 : T.helpers_edge;
   const int edge_tiles = (d.n_rows + kHRows - 1) / kHRows;
   const bool edge = edge_rule != 0 && MODE == GC_MODE_MLP_LN && ONEPASS == 0 && d.seg && d.out && d.g0 && d.g1 && !d.d && d.b1 &&
                     d.k0 + d.k1 > 0 && edge_tiles > GC_SCRATCH_SLOTS / 2 && (edge_rule == 2 || edge_tiles <= GC_HELPERS_EDGE_MAX_TILES);
@@ -874,15 +890,9 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
 }
 
 // The eight-wave "helper waves" form of the same launch (csrc/rowmlp_half.inc: rowmlp16d_kernel): ONE persistent
-// workgroup per CU.  gc_rowmlp_desc.flags GC_WG_HELPERS asks for it per launch, GCAST_HELPERS=1|0 (read once) for a
-// whole process.
-int half_helpers_default() {
-  static const int v = [] {
-    const char* e = std::getenv("GCAST_HELPERS");
-    return e ? std::atoi(e) : GC_HELPERS_DEFAULT;
-  }();
-  return v;
-}
+// workgroup per CU.  gc_rowmlp_desc.flags GC_WG_HELPERS asks for it per launch, gc_tuning.helpers = 1 | 0 for every
+// launch that does not pin a form.
+int half_helpers_default() { return tuning().helpers == 1; }
 
 template <int MODE, int ONEPASS, int HST>
 int launch_rowmlp_half_d2(const gc_rowmlp_desc& d, hipStream_t s) {
@@ -908,12 +918,12 @@ int launch_rowmlp_half_d2(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlp16d_kernel");
 }
 
-template <int MODE>
+template <int MODE, int ONEPASS>
 int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s) {
-  const size_t lds = kHLdsFloats * sizeof(float);
+  const size_t lds = kWLdsFloats * sizeof(float);     // four-wave layout + the parking area (LDS share of the parked accumulators / second sub-tile)
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16w_kernel<MODE>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16w_kernel<MODE, ONEPASS>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
@@ -928,7 +938,7 @@ int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s) {
   dd.flags &= ~GC_TILE_XCD;
   if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
   apply_prio(dd);
-  hipLaunchKernelGGL((rowmlp16w_kernel<MODE>), dim3(grid), dim3(512), lds, s, dd);
+  hipLaunchKernelGGL((rowmlp16w_kernel<MODE, ONEPASS>), dim3(grid), dim3(512), lds, s, dd);
   return check_launch("rowmlp16w_kernel");
 }
 
@@ -937,9 +947,9 @@ int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s) {
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
   if constexpr (MODE == GC_MODE_MLP_LN) {
-    // GCAST_HELPER_STORE=0|1|2 (read once; A/B): 0 = the staging waves only stage, 1 = + residual / store, 2 (default)
+    // gc_tuning.helper_store = 0|1|2 (A/B): 0 = the staging waves only stage, 1 = + residual / store, 2 (default)
     // = + the gather of the next tile's addends, where the launch has the shape for it (two-pass, b1 + g0 + g1)
-    static const int hst_max = [] { const char* e = std::getenv("GCAST_HELPER_STORE"); return e ? std::atoi(e) : 2; }();
+    const int hst_max = tuning().helper_store;
     if (hst_max >= 1 && d.seg && d.out) {
       if constexpr (ONEPASS == 0)
         if (hst_max >= 2 && d.g0 && d.g1 && !d.d && d.b1 && d.k0 + d.k1 > 0)
@@ -956,15 +966,9 @@ bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};
 // one weight stream, one workgroup per CU) for the big node-side launches -- no gather, no segment-sum,
 // at least kBfWideMinRows rows: measured 6-7 % faster there, 1-7 % slower on the edge updates
 // (profiles/r03_s12_*).  gc_rowmlp_desc.flags GC_WG_ROWS_64 / _128 pin the choice per launch,
-// GCAST_BF16_ROWS=64|128 (read once) for a whole process (A/B runs of bench.py).
+// gc_tuning.bf16_rows = 64 | 128 for every launch that does not pin one (A/B runs of bench.py).
 constexpr int kBfWideMinRows = 128 * 256 * 2;
-int bf16_rows_override() {
-  static const int v = [] {
-    const char* e = std::getenv("GCAST_BF16_ROWS");
-    return e ? std::atoi(e) : 0;
-  }();
-  return v;
-}
+int bf16_rows_override() { return tuning().bf16_rows; }
 
 template <bool F32ROWS, int NW>
 int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
@@ -1060,8 +1064,8 @@ int gc_rowmlp(const gc_rowmlp_desc* dp, void* stream) {
   if (!dp) return fail(GC_EINVAL, "gc_rowmlp: null descriptor");
   gc_rowmlp_desc d = *dp;
   // gc_rowmlp_desc.tile_queue: the persistent kernels' dynamic tile queue (GC_LAYOUT_HALF launches and the
-  // GC_PREC_BF16 tier); GCAST_TILE_QUEUE=0 (read once) walks the tiles statically whatever the descriptor says (A/B).
-  static const bool queue_off = [] { const char* e = std::getenv("GCAST_TILE_QUEUE"); return e && std::atoi(e) == 0; }();
+  // GC_PREC_BF16 tier); gc_tuning.tile_queue = 0 walks the tiles statically whatever the descriptor says (A/B).
+  const bool queue_off = !tuning().tile_queue;
   if (d.tile_queue && (reinterpret_cast<size_t>(d.tile_queue) & 7))
     return fail(GC_EINVAL, "gc_rowmlp: tile_queue must be an 8-byte aligned pair of device words");
   if (d.tile_queue && d.prec != GC_PREC_BF16 && d.layout != GC_LAYOUT_HALF)
@@ -1322,10 +1326,33 @@ int gc_time_program(const gc_op* ops, int n_ops, int iters, float* h_ms, void* s
 
 size_t gc_abi_sizeof(int what) {
   return what == 0 ? sizeof(gc_rowmlp_desc) : what == 1 ? sizeof(gc_op)
-         : what == 2 ? sizeof(gc_advance_desc) : what == 3 ? sizeof(gc_model_desc) : 0;
+         : what == 2 ? sizeof(gc_advance_desc) : what == 3 ? sizeof(gc_model_desc) : what == 4 ? sizeof(gc_tuning) : 0;
 }
 
 const char* gc_last_error(void) { return g_err; }
+
+int gc_get_tuning(gc_tuning* out) {
+  if (!out) return fail(GC_EINVAL, "gc_get_tuning: null pointer");
+  *out = tuning();
+  return 0;
+}
+int gc_set_tuning(const gc_tuning* t) {
+  if (!t) return fail(GC_EINVAL, "gc_set_tuning: null pointer");
+  if (!tuning_valid(*t)) return fail(GC_EINVAL, "gc_set_tuning: a value is outside its range (include/gcast.h: gc_tuning)");
+  tuning_mut() = *t;
+  return 0;
+}
+const char* gc_tuning_string(const gc_tuning* tp) {
+  static thread_local char buf[512];
+  const gc_tuning& t = tp ? *tp : tuning();
+  std::snprintf(buf, sizeof(buf),
+                "grid_cap=%d;tile_map=%s;prio=%d,%d,%d%s;helpers=%d;helpers_small=%d;helpers_edge=%d;helper_store=%d;"
+                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d",
+                t.grid_cap, t.tile_map_xcd ? "xcd" : "rr", t.prio_gemm, t.prio_other, t.prio_stage, t.prio_set ? "(set)" : "",
+                t.helpers, t.helpers_small, t.helpers_edge, t.helper_store, t.helpers_min_rows, t.wide, t.wide_edges, t.bf16_rows,
+                t.tile_queue, t.fuse, t.onepass);
+  return buf;
+}
 
 #include "gcast_plan.inc"
 

@@ -32,7 +32,6 @@ from graphcast_amd import packing
 from graphcast_amd.launch import DEFAULT_PRECISION, TAGS, _Edges, _Mlp, _PW, _chained    # noqa: F401  (re-exported)
 
 D = packing.LATENT
-DEFAULT_HELPERS_MIN_ROWS = "65536"     # = GC_HELPERS_MIN_ROWS_DEFAULT (include/gcast.h); see StepEngine.helpers_min_rows
 
 _EDGE_TAGS = {TAGS["enc_edge"]: "g2m", TAGS["proc_edge"]: "mesh", TAGS["dec_edge"]: "m2g"}
 _WORKSPACE_TENSORS = ("xin", "h_grid", "pre_grid", "h_grid2", "agg_grid", "h_mesh", "agg_mesh", "pre_s_mesh",
@@ -106,11 +105,10 @@ class StepEngine(launch.LaunchBase):
     if half is False and self.prec == nat.PREC_F16X3:
       raise ValueError("half=False: the chunked f16x3 kernels were retired in round 5 (f16x3 runs the half-N kernels)")
     self.half = self.prec in (nat.PREC_F16X3, nat.PREC_BF16)
-    self.fuse = self.half and (os.environ.get("GCAST_FUSE", "1") == "1" or self.prec == nat.PREC_BF16)
-    # GCAST_HELPERS_MIN_ROWS=<n>: launches without gather / segment-sum from n rows on run in the helper-wave form
-    # (0 = never; DESIGN.md section 9.7: the grid-sized node launches are 3-5 % faster in it, profiles/r04_s7_*).
-    # The plan applies the same default; the attribute lets a caller (smoke(), tests) change it per engine.
-    self.helpers_min_rows = int(os.environ.get("GCAST_HELPERS_MIN_ROWS", DEFAULT_HELPERS_MIN_ROWS))
+    # The speed-only switches come from the library's ONE tuning surface (include/gcast.h: gc_tuning; the GCAST_*
+    # variables only initialise its process default): the plan snapshots it at creation, the engine reads the snapshot
+    # back below.  helpers_min_rows: launches without gather / segment-sum from that many rows on run as one eight-wave
+    # workgroup per CU (0 = never); the attribute lets a caller (smoke(), tests) change it per engine.
     self.wide_min_rows = None      # (None: the plan's choice.  An int: two-pass MLP launches without gather / segment-sum
     #                                 from that many rows on run in the wide form -- smoke(), tests)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
@@ -120,6 +118,10 @@ class StepEngine(launch.LaunchBase):
     self._views = {}
     self._plan = create_plan(self.lib, graphs, params, num_steps=num_steps, c_in=c_in, c_out=c_out,
                              precision=precision, device=self.dev)
+    self.tuning = nat.Tuning()
+    nat.check(self.lib.gc_plan_get_tuning(self._plan, ctypes.byref(self.tuning)), "gc_plan_get_tuning")
+    self.fuse = self.half and (bool(self.tuning.fuse) or self.prec == nat.PREC_BF16)
+    self.helpers_min_rows = self._plan_helpers_min_rows = int(self.tuning.helpers_min_rows)
     with torch.cuda.device(self.dev):
       self._ws = torch.empty(self.lib.gc_plan_workspace_bytes(self._plan, 1), dtype=torch.uint8, device=self.dev)
     # the f16x3 kernels' range word (include/gcast.h: gc_rowmlp_desc.range_flag) and the persistent kernels' tile queue:
@@ -197,7 +199,7 @@ class StepEngine(launch.LaunchBase):
     # without gather / segment-sum from that many rows on into the eight-wave HELPER form (smoke(), tests)
     # -- or, with `wide_min_rows` set, into the WIDE form where the launch has the shape for it.
     if (self.wide_min_rows is not None
-        or self.helpers_min_rows != int(os.environ.get("GCAST_HELPERS_MIN_ROWS", DEFAULT_HELPERS_MIN_ROWS))):
+        or self.helpers_min_rows != self._plan_helpers_min_rows):
       for k in range(n.value):
         m = ops[k].mlp
         if (ops[k].kind == nat.OP_ROWMLP and m.layout == nat.LAYOUT_HALF and m.prec == nat.PREC_F16X3

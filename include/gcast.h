@@ -110,10 +110,10 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /
                                   * waves, four waves that stage the weight ring for them (csrc/rowmlp_half.inc:
                                   * rowmlp16d_kernel) -- instead of two four-wave workgroups.  Bit-identical results. */
 #define GC_WG_NO_HELPERS 64      /* ... or pin the four-wave form (neither flag: the build's default, GC_HELPERS_DEFAULT) */
-#define GC_WG_WIDE 256           /* GC_LAYOUT_HALF, GC_MODE_MLP_LN launches without a segment-sum: ONE workgroup of eight
-                                  * MULTIPLYING waves per CU -- 128 rows against one weight ring, half the L2 -> LDS
-                                  * stream per row (csrc/rowmlp_half.inc: rowmlp16w_kernel).  Same bits.  Ignored where
-                                  * the launch has a segment-sum or is not a two-pass GC_MODE_MLP_LN launch. */
+#define GC_WG_WIDE 256           /* GC_LAYOUT_HALF, GC_MODE_MLP_LN launches: ONE workgroup of eight MULTIPLYING waves per
+                                  * CU -- 128 rows against one weight ring, half the L2 -> LDS stream per row
+                                  * (csrc/rowmlp_half.inc: rowmlp16w_kernel).  Same bits.  Round 6: also launches with a
+                                  * segment-sum and the one-pass (GC_W2_NATURAL) ones.  Ignored in other modes. */
 #define GC_WIDE_MIN_ROWS 262144   /* the plan asks for GC_WG_WIDE from this many rows on (>= 8 rounds of 256 128-row tiles:
                                   * below, the doubled tail costs more than the shared ring saves) */
 #define GC_TILE_QUEUE_ANY 128    /* gc_rowmlp_desc.tile_queue: hand the tiles out dynamically whenever the launch has more
@@ -474,7 +474,48 @@ int gc_host_pack_edges(int n_edges, const int* h_senders, const int* h_receivers
                        long long* h_perm, int* h_snd, int* h_rcv, int* h_flags,
                        int* h_fix, int* n_fix, int* h_empty, int* n_empty);
 
-/* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for 1, sizeof(gc_advance_desc) for 2, sizeof(gc_model_desc) for 3, 0 otherwise:
+/* ONE tuning surface (round 6).  Every speed-only A/B switch of the library -- which kernel FORM a launch runs in, the
+ * persistent grid, the tile schedule, wave priorities, which algebraic fusions the plan's program uses -- lives in this
+ * struct.  None of them changes a result bit (tests/test_rowmlp_gpu.py, tests/test_step_gpu.py run the forms against
+ * each other).  The GCAST_* environment variables named below are read ONCE, the first time the library needs a
+ * tuning, and only INITIALISE the process default; after that the environment is never consulted again.
+ *   gc_get_tuning / gc_set_tuning   the process default: what gc_rowmlp / gc_run_program use for a descriptor that does
+ *                                   not pin its own form in gc_rowmlp_desc.flags, and what gc_plan_create snapshots.
+ *                                   (Not synchronised against launches running on other host threads.)
+ *   gc_plan_get_tuning              the snapshot a plan was created with: its program's fusions and the form pinned into
+ *                                   every op of gc_plan_program / gc_step_forward -- later gc_set_tuning calls do not
+ *                                   reach an existing plan's plan-level choices.
+ *   gc_tuning_string                "grid_cap=512;tile_map=rr;prio=1,0,0;..." of a tuning (NULL: the process default),
+ *                                   for logs and bench.py's line; thread-local storage, valid until the next call. */
+typedef struct gc_tuning {
+  int grid_cap;          /* GCAST_GRID_CAP: persistent workgroups per GC_LAYOUT_HALF launch, 1 .. GC_SCRATCH_SLOTS (512) */
+  int tile_map_xcd;      /* GCAST_TILE_MAP=xcd: every XCD walks a contiguous eighth of the tiles (GC_TILE_XCD); default 0 */
+  int prio_set;          /* GCAST_PRIO was given: its three values also apply to the GC_PREC_BF16 kernels (default there 0,0,0) */
+  int prio_gemm, prio_other, prio_stage;   /* GCAST_PRIO="g,o,s": s_setprio levels (GC_PRIO); default 1,0,0 */
+  int helpers;           /* GCAST_HELPERS: -1 unset (the rules below decide), 0 = four-wave form everywhere, 1 = eight-wave helper form everywhere */
+  int helpers_small;     /* GCAST_HELPERS_SMALL: node-side launches of <= one tile per CU in the helper form; default 1 */
+  int helpers_edge;      /* GCAST_HELPERS_EDGE: the processor edge update in the HST form: 0 never, 1 = 257 .. GC_HELPERS_EDGE_MAX_TILES tiles (default), 2 at every size */
+  int helper_store;      /* GCAST_HELPER_STORE: what the staging waves of that form take over: 0 nothing, 1 residual + store, 2 + next tile's gather (default) */
+  int helpers_min_rows;  /* GCAST_HELPERS_MIN_ROWS: plan: launches without gather / segment-sum from this many rows on run one eight-wave workgroup per CU; 0 never */
+  int wide;              /* GCAST_WIDE: plan: ... in the WIDE form from GC_WIDE_MIN_ROWS rows on (default 1), else the helper form */
+  int wide_edges;        /* GCAST_WIDE_EDGES (round 6): edge updates (segment-sum launches) in the WIDE form: bit 0 the one-pass ones
+                            (encoder / decoder edge update, processor step 0), bit 1 the two-pass ones; from GC_WIDE_EDGE_MIN_TILES tiles on */
+  int bf16_rows;         /* GCAST_BF16_ROWS: 0 = by rule, 64 | 128 = every GC_PREC_BF16 launch with that many rows per workgroup */
+  int tile_queue;        /* GCAST_TILE_QUEUE: 0 = static tile walk whatever the descriptor says; default 1 */
+  int fuse;              /* GCAST_FUSE: plan: the chained launch program (default 1); 0 = one launch per reference layer group */
+  int onepass;           /* GCAST_ONEPASS: plan: one-pass edge updates where the first layer is all addends (default 1) */
+  int reserved[8];
+} gc_tuning;
+int gc_get_tuning(gc_tuning* out);
+int gc_set_tuning(const gc_tuning* t);          /* GC_EINVAL (and no change) for a value outside its range */
+int gc_plan_get_tuning(const gc_plan* plan, gc_tuning* out);
+const char* gc_tuning_string(const gc_tuning* t);
+#define GC_WIDE_EDGE_MIN_TILES 4096   /* 64-row tiles: >= 8 rounds of 256 wide tiles */
+#ifndef GC_WIDE_EDGES_DEFAULT
+#define GC_WIDE_EDGES_DEFAULT 0       /* gc_tuning.wide_edges of a process that does not set GCAST_WIDE_EDGES */
+#endif
+
+/* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for 1, sizeof(gc_advance_desc) for 2, sizeof(gc_model_desc) for 3, sizeof(gc_tuning) for 4, 0 otherwise:
  * lets a foreign-language binding verify its struct layout at load time. */
 size_t gc_abi_sizeof(int what);
 

@@ -1,0 +1,33 @@
+#!/bin/bash
+# The GPU-box sessions of round 6 in ONE file: `bash scripts/r06_sessions.sh <name>` runs one of them from the repository
+# root; results land under gpurun_out/r06_<name>/, what is kept is copied to profiles/r06_<name>_*.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+NAME=${1:?session name}
+OUT=gpurun_out/r06_$NAME; mkdir -p "$OUT"
+export TMPDIR=/tmp
+gate() { grep -q " passed" "$1" && ! grep -q "failed\|rror\|Timeout" "$1" || { echo "GATE: $2 failed"; tail -40 "$1"; exit 1; }; }
+show() { python - "$1" <<'PY'
+import json, sys
+try:
+  j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+  print("no bench line:", e); sys.exit(0)
+print(round(j["ms_per_step"], 3), {k: round(v["ms"], 3) for k, v in (j.get("roofline") or {}).get("stages", {}).items()})
+for k in ("rollout", "rollout_api"):
+  if j.get(k): print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in j[k].items() if a != "what"})
+print("tuning", j.get("tuning"))
+PY
+}
+case "$NAME" in
+  s1)
+    # Round-6 session 1: the wide form widened -- ten of sixteen parked n-blocks in LDS (GC_W_PARK_NB; A/B library with
+    # 0 = round 5's parking), segment-sum launches and the one-pass edge updates in the form (gc_tuning.wide_edges /
+    # GCAST_WIDE_EDGES: bit 0 one-pass, bit 1 two-pass) -- bit-identity first, then same-session A/B of the whole step.
+    timeout 1500 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_step_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -5 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "wide form with segment-sum / one-pass / LDS parking"
+    bash scripts/session.sh bench-ab r06_s1 "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_WIDE_EDGES=2" "GCAST_WIDE_EDGES=3" \
+        "GCAST_LIB_PATH=ab_libs/libgcast_wpark0.so" "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_LIB_PATH=ab_libs/libgcast_wpark0.so"
+    ;;
+  *) echo "unknown session $NAME"; exit 2;;
+esac

@@ -44,7 +44,61 @@ def test_struct_layout_matches_header(built):
   assert lib.gc_abi_sizeof(1) == ctypes.sizeof(nat.Op)
   assert lib.gc_abi_sizeof(2) == ctypes.sizeof(nat.AdvanceDesc)
   assert lib.gc_abi_sizeof(3) == ctypes.sizeof(nat.ModelDesc)      # (round 5: + the halo-table sizes)
-  assert lib.gc_abi_sizeof(4) == 0
+  assert lib.gc_abi_sizeof(4) == ctypes.sizeof(nat.Tuning)         # (round 6: the one tuning surface)
+  assert lib.gc_abi_sizeof(5) == 0
+
+
+def test_tuning_is_one_struct_set_and_read_back(built):
+  """include/gcast.h: gc_tuning -- every speed-only switch of the library in ONE struct.  The
+  GCAST_* variables initialise the process default once; afterwards the struct is what the launch functions read:
+  a host sets it, reads it back, and a value outside its range is refused without changing anything."""
+  lib = built.lib()
+  before = nat.get_tuning()
+  d = before.as_dict()
+  assert set(d) == {"grid_cap", "tile_map_xcd", "prio_set", "prio_gemm", "prio_other", "prio_stage", "helpers",
+                    "helpers_small", "helpers_edge", "helper_store", "helpers_min_rows", "wide", "wide_edges", "bf16_rows",
+                    "tile_queue", "fuse", "onepass"}
+  if not any(k.startswith("GCAST_") for k in os.environ):      # the documented defaults of a process without overrides
+    assert d == dict(grid_cap=512, tile_map_xcd=0, prio_set=0, prio_gemm=1, prio_other=0, prio_stage=0, helpers=-1,
+                     helpers_small=1, helpers_edge=1, helper_store=2, helpers_min_rows=65536, wide=1,
+                     wide_edges=nat.WIDE_EDGES_DEFAULT, bf16_rows=0, tile_queue=1, fuse=1, onepass=1)
+  try:
+    prev = nat.set_tuning(grid_cap=256, helpers_edge=2, wide_edges=3, prio_gemm=2)
+    assert bytes(prev) == bytes(before)
+    now = nat.get_tuning().as_dict()
+    assert (now["grid_cap"], now["helpers_edge"], now["wide_edges"], now["prio_gemm"]) == (256, 2, 3, 2)
+    assert {k: v for k, v in now.items() if k not in ("grid_cap", "helpers_edge", "wide_edges", "prio_gemm")} == \
+           {k: v for k, v in d.items() if k not in ("grid_cap", "helpers_edge", "wide_edges", "prio_gemm")}
+    s = nat.tuning_string()
+    assert "grid_cap=256" in s and "helpers_edge=2" in s and "wide_edges=3" in s and "prio=2,0,0" in s
+    # the environment is NOT consulted again: a variable set now changes nothing
+    os.environ["GCAST_GRID_CAP"] = "17"
+    try:
+      assert nat.get_tuning().grid_cap == 256
+    finally:
+      del os.environ["GCAST_GRID_CAP"]
+    bad = nat.get_tuning()
+    bad.grid_cap = 0
+    assert lib.gc_set_tuning(ctypes.byref(bad)) == nat.EINVAL and b"outside its range" in lib.gc_last_error()
+    assert nat.get_tuning().grid_cap == 256
+    with pytest.raises(KeyError):
+      nat.set_tuning(no_such_field=1)
+  finally:
+    nat.set_tuning(before)
+  assert bytes(nat.get_tuning()) == bytes(before)
+
+
+def test_no_getenv_inside_a_launch_function():
+  """The only getenv calls of the library sit in tuning_from_env() (csrc/gcast.hip), the default initialiser."""
+  src = open(os.path.join(ROOT, "graphcast_amd", "csrc", "gcast.hip")).read()
+  body = src[src.index("gc_tuning tuning_from_env() {"):]
+  body = body[:body.index("\n}\n") + 3]
+  for f in ("gcast.hip", "gcast_plan.inc", "rowmlp_half.inc", "rowmlp_bf16.inc"):
+    text = open(os.path.join(ROOT, "graphcast_amd", "csrc", f)).read()
+    if f == "gcast.hip":
+      text = text.replace(body, "")
+    code = "\n".join(line.split("//")[0] for line in text.splitlines())
+    assert "getenv" not in code, f
 
 
 def test_argument_validation_needs_no_gpu(built):

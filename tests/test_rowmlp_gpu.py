@@ -320,6 +320,13 @@ def test_edge_block_with_segment_sum(dev, case):
   agg.fill_(float("nan")); out.zero_()
   pipeline()
   assert torch.equal(first, agg) and torch.equal(first_out, out)
+  # round 6: the WIDE form takes launches with a segment-sum too (GC_WG_WIDE: eight multiplying waves on one weight ring;
+  # the 128-row tile's two 64-row sub-tiles run their segment-sums side by side; "skewed" / "with_empty" have an ODD
+  # number of 64-row tiles -- the last wide tile's second half has no rows): the same bits, rows and aggregate
+  d.flags = nat.WG_WIDE
+  agg.fill_(float("nan")); out.zero_()
+  pipeline()
+  assert torch.equal(first, agg) and torch.equal(first_out, out)
   d.flags = 0
   # round 4: with the dynamic tile queue (more tiles than workgroups in "many_tiles"; a no-op otherwise) the
   # segment-sum's partial rows are still addressed by the TILE: the same bits whichever workgroup ran it
@@ -359,6 +366,13 @@ def test_edge_block_with_segment_sum(dev, case):
     pipeline()
     assert torch.equal(again, agg)
     assert torch.equal(helper_bits[0], agg) and torch.equal(helper_bits[1], out)
+    # round 6: the one-pass launch in the WIDE form (128 rows per weight ring), statically walked and through the queue
+    for wide_flags in (nat.W2_NATURAL | nat.WG_WIDE, nat.W2_NATURAL | nat.WG_WIDE | nat.TILE_QUEUE_ANY):
+      d.flags = wide_flags
+      agg.fill_(float("nan")); out.zero_()
+      pipeline()
+      assert torch.equal(helper_bits[0], agg) and torch.equal(helper_bits[1], out), (case, with_g1, wide_flags)
+      assert queue.tolist() == [0, 0]
 
 
 @pytest.mark.parametrize("n_rows,n2,batch", [(64, 227, 1), (500, 83, 2), (70, 240, 1)])
@@ -767,8 +781,10 @@ def test_processor_edge_update_in_both_kernel_forms(dev, n_recv):
   has = np.bincount(pk.receivers[ok], minlength=n_recv) > 0
   got = ref_agg.cpu().numpy()
   assert np.linalg.norm(got[has] - want[has]) <= 2 * REL_RMSE_TOL[_PREC] * np.linalg.norm(want[has])
+  # (round 6: ... and in the WIDE form, whose two-pass launches park ten of sixteen n-blocks in LDS)
   for flags, with_queue in ((nat.WG_HELPERS, False), (nat.WG_HELPERS | nat.TILE_QUEUE_ANY, True),
-                            (nat.WG_NO_HELPERS | nat.TILE_QUEUE_ANY, True), (nat.WG_HELPERS, False)):
+                            (nat.WG_NO_HELPERS | nat.TILE_QUEUE_ANY, True), (nat.WG_HELPERS, False),
+                            (nat.WG_WIDE, False), (nat.WG_WIDE | nat.TILE_QUEUE_ANY, True)):
     got_e, got_agg = pipeline(flags, with_queue)
     assert torch.equal(got_e, ref_e), (flags, with_queue, float((got_e - ref_e).abs().max()))
     assert torch.equal(got_agg[torch.from_numpy(has).to(dev)], ref_agg[torch.from_numpy(has).to(dev)]), (flags, with_queue)
