@@ -150,10 +150,21 @@ class GraphCast(predictor_base.Predictor):
     prev = self._precision
     if precision != prev:
       if self._engine is not None:
+        # (a non-blocking range check of the engine being put aside must not stay pending for ever: ADVICE r5)
+        self._engine.check_range(wait=True)
         self._engines[prev] = self._engine
       self._engine = self._engines.get(precision)
       self._precision = precision
     return prev
+
+  def check_range(self) -> None:
+    """Blocks until the steps enqueued so far are done and raises ``GcastRangeError`` if one of them read a value
+    outside the exact range of the f16x3 arithmetic.  ``__call__`` on device-resident Datasets only SCHEDULES that
+    check (it must not make the host wait once per step); callers that keep everything on the device call this -- or
+    ``launch.flush_range_checks()`` -- where they synchronise anyway.  ``rollout._to_host``, the end of
+    ``rollout.chunked_prediction_generator`` and ``set_precision`` do."""
+    if self._engine is not None:
+      self._engine.check_range(wait=True)
 
   @property
   def _finest_mesh(self):
@@ -305,8 +316,9 @@ class GraphCast(predictor_base.Predictor):
     # the f16x3 arithmetic is exact only for |x| <= 65504 (normalised inputs are O(1)); the reference's fp32 takes
     # anything: a step fed e.g. un-normalised geopotential RAISES here instead of returning wrong numbers.  (A
     # synchronisation point on the host path, which copies y back right below; device-resident Datasets are checked
-    # WITHOUT waiting: the flag is copied to pinned memory behind the step and tested at the next call -- the launches
-    # never clear it.)
+    # WITHOUT waiting: the flag is copied to pinned memory behind the step and tested at the next call or at the host's
+    # next synchronisation point -- rollout._to_host, the end of a chunked rollout, set_precision, check_range() --
+    # whichever comes first; the launches never clear it.)
     self._engine.check_range(wait=host_in or not on_device)
     if host_in and on_device:
       # host Datasets in -> host Datasets out: ONE D2H copy of the contiguous [N_grid, B, C_out] block into pinned

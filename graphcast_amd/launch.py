@@ -7,6 +7,7 @@ step itself is NOT recorded here: its one launch program lives in csrc/gcast_pla
 ``engine.StepEngine`` drives that.  All arithmetic happens in libgcast_hip.so; torch only owns the memory.
 """
 import ctypes
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -22,6 +23,17 @@ DEFAULT_PRECISION = "f16x3"
 TAGS = dict(prep=0, enc_embed_grid=1, enc_pre=2, enc_edge=3, enc_node_mesh=4, enc_node_grid=5,
             proc_pre=6, proc_edge=7, proc_node=8, dec_pre=9, dec_edge=10, dec_node=11,
             dec_out=12, fixup=13)
+
+
+# Engines whose last range check was the non-blocking kind (LaunchBase.check_range(wait=False)): its verdict is still
+# pending.  flush_range_checks() settles them -- called wherever the host synchronises anyway.
+_pending_range_checks = weakref.WeakSet()
+
+
+def flush_range_checks():
+  """The blocking range check on every engine that has a non-blocking one pending (raises GcastRangeError)."""
+  for engine in list(_pending_range_checks):
+    engine.check_range(wait=True)
 
 
 class _PW:
@@ -251,7 +263,6 @@ class LaunchBase:
                       ln=(mlp.scale, mlp.offset), w2_natural=getattr(mlp, "w2_natural", None), **kw)
 
   _range_pending = None
-  _range_pending = None
 
   def check_range(self, wait: bool = True):
     """Raises GcastRangeError if a step since the last call read an input value, or an AGGREGATE (the layer-1 operand
@@ -261,13 +272,17 @@ class LaunchBase:
     the reference's fp32 does not care; un-normalised geopotential is ~5e5).  SYNCHRONISES the launch stream:
     call it where the host waits for the step anyway (GraphCast.__call__ on host Datasets, DeviceRollout.run,
     bench.py do); ``wait=False`` never blocks (a device-resident Dataset rollout must not wait on the host
-    once per step)."""
+    once per step): the verdict of such a call is PENDING until the next call on this engine or -- round 6, ADVICE r5 --
+    the host's next real synchronisation point, whichever comes first: ``flush_range_checks()`` (module level) runs the
+    blocking check on every engine with a pending one, and ``rollout._to_host`` (the reference's ``jax.device_get``), the
+    end of ``rollout.chunked_prediction_generator`` and ``GraphCast.set_precision`` call it."""
     if self.range_flag is None:
       return
     if not wait:
       # device-resident callers (torch-backed Datasets: nothing else makes the host wait): the word is copied to pinned
       # memory behind the step and tested at the NEXT call -- the launches never clear it, so an out-of-range step is
-      # reported one call late at worst (and at the latest by the first blocking check: to_host, DeviceRollout.run)
+      # reported one call late at worst (and at the latest by the first blocking check: flush_range_checks above)
+      _pending_range_checks.add(self)
       if self._range_pending is not None:
         host, done = self._range_pending
         if not done.query():
@@ -283,8 +298,12 @@ class LaunchBase:
         done.record(torch.cuda.current_stream(self.dev))
         self._range_pending = (host, done)
         return
-    elif int(self.range_flag.item()) == 0:
-      return
+    else:
+      _pending_range_checks.discard(self)
+      self._range_pending = None
+      if int(self.range_flag.item()) == 0:
+        return
+    _pending_range_checks.discard(self)
     self._range_pending = None
     self.range_flag.zero_()
     raise nat.GcastRangeError(

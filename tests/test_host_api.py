@@ -8,6 +8,7 @@ stacked inputs behind the Predictor interface: the device step has its own GPU
 parity tests; these tests pin the plumbing (channel order, rolling window,
 coordinates, error behaviour) that the reference leaves untested."""
 import io
+import os
 import dataclasses
 from typing import Any, Optional
 
@@ -808,12 +809,28 @@ def test_fused_rollout_recognises_the_demo_stack_and_nothing_else():
   found = rollout._fused_stack(rollout.as_predictor_fn(stack))
   assert found is not None and found.model is model and not found.verify and found.tier is None and not found.time_leading
   assert found.std is stack._state_stats[0] and found.mean is stack._state_stats[1] and found.dstd is stack._residual_stats[0]
-  # closures, partials: found, but to be cross-checked
-  for fn in (lambda rng, **kw: stack(**kw),
-             functools.partial(lambda predictor, rng, **kw: predictor(**kw), stack),
-             functools.partial(lambda rng, predictor=None, **kw: predictor(**kw), predictor=stack)):
-    found = rollout._fused_stack(fn)
+  # closures, partials: OPAQUE by default (round 6: the reference's contract, utils/rollout.py:78-87) -- looked into only
+  # behind the caller's opt-in rollout.fuse(fn) (or GCAST_ROLLOUT_FUSED=closures), and then to be cross-checked
+  closures = (lambda rng, **kw: stack(**kw),
+              functools.partial(lambda predictor, rng, **kw: predictor(**kw), stack),
+              functools.partial(lambda rng, predictor=None, **kw: predictor(**kw), predictor=stack),
+              lambda rng, **kw: rollout.as_predictor_fn(stack)(rng, **kw))
+  for fn in closures:
+    assert rollout._fused_stack(fn) is None
+    found = rollout._fused_stack(rollout.fuse(fn))
     assert found is not None and found.model is model and found.verify
+    assert rollout.fuse(rollout.fuse(fn)) is not None and rollout._fused_stack(rollout.fuse(rollout.fuse(fn))).verify
+  os.environ["GCAST_ROLLOUT_FUSED"] = "closures"
+  try:
+    assert all(rollout._fused_stack(fn) is not None and rollout._fused_stack(fn).verify for fn in closures)
+  finally:
+    os.environ["GCAST_ROLLOUT_FUSED"] = "0"
+  try:
+    assert rollout._fused_stack(rollout.fuse(closures[0])) is None and rollout._fused_stack(rollout.as_predictor_fn(stack)) is None
+  finally:
+    del os.environ["GCAST_ROLLOUT_FUSED"]
+  trusted = rollout.as_predictor_fn(stack)
+  assert rollout.fuse(trusted) is trusted and not rollout._fused_stack(rollout.fuse(trusted)).verify
   # the reference's full chain: autoregressive outermost (time-leading outputs), Bfloat16Cast inside the normalisation
   full = autoregressive.Predictor(normalization.InputsAndResiduals(casting.Bfloat16Cast(model), std, mean, dstd))
   found = rollout._fused_stack(rollout.as_predictor_fn(full))
@@ -821,10 +838,10 @@ def test_fused_rollout_recognises_the_demo_stack_and_nothing_else():
   off = normalization.InputsAndResiduals(casting.Bfloat16Cast(model, enabled=False), std, mean, dstd)
   assert rollout._fused_stack(rollout.as_predictor_fn(off)).tier is None
   # a closure that holds the stack AND its inner model still has ONE outermost stack
-  assert rollout._fused_stack(lambda rng, **kw: (model, stack)[1](**kw)).model is model
+  assert rollout._fused_stack(rollout.fuse(lambda rng, **kw: (model, stack)[1](**kw))).model is model
   # not recognised
   toy = _toy()
-  assert rollout._fused_stack(lambda rng, **kw: toy(**kw)) is None
+  assert rollout._fused_stack(rollout.fuse(lambda rng, **kw: toy(**kw))) is None
   assert rollout._fused_stack(rollout.as_predictor_fn(model)) is None                     # bare GraphCast
   assert rollout._fused_stack(rollout.as_predictor_fn(normalization.InputsAndResiduals(toy, std, mean, dstd))) is None
   cpu_model = gcm.GraphCast(cfg, gcm.TASK_13, device="cpu")
@@ -838,5 +855,5 @@ def test_fused_rollout_recognises_the_demo_stack_and_nothing_else():
   assert rollout._fused_stack(rollout.as_predictor_fn(Extra(stack))) is None
   assert rollout._fused_stack(rollout.as_predictor_fn(normalization.InputsAndResiduals(Extra(model), std, mean, dstd))) is None
   other = normalization.InputsAndResiduals(gcm.GraphCast(cfg, gcm.TASK_13, device="cuda:0"), std, mean, dstd)
-  assert rollout._fused_stack(lambda rng, **kw: (stack if rng else other)(**kw)) is None  # two stacks: ambiguous
-  assert rollout._fused_stack(print) is None and rollout._fused_stack(None) is None
+  assert rollout._fused_stack(rollout.fuse(lambda rng, **kw: (stack if rng else other)(**kw))) is None  # two stacks: ambiguous
+  assert rollout._fused_stack(print) is None and rollout._fused_stack(None) is None and rollout._fused_stack(rollout.fuse(print)) is None

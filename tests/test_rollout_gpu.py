@@ -303,25 +303,61 @@ def test_chunked_prediction_runs_the_fused_device_loop_under_a_recognised_stack(
   np.testing.assert_array_equal(got.coords["time"].values, generic.coords["time"].values)
   if "datetime" in generic.coords:
     np.testing.assert_array_equal(got.coords["datetime"].values, generic.coords["datetime"].values)
-  # (2) a closure around the stack (how the reference's users write predictor_fn): found, cross-checked, fused
+  # (2) a closure around the stack (how the reference's users write predictor_fn) is OPAQUE by default (round 6;
+  #     reference utils/rollout.py:78-87, :534-538): it is called for EVERY chunk, whatever it closes over -- a closure
+  #     that logs or saves every chunk sees all of them
   calls = []
   def fn(rng, inputs, targets_template, forcings):
     calls.append(1)
     return stack(inputs, targets_template, forcings)
-  _equal_datasets(rollout.chunked_prediction(fn, None, inputs, template, forcings), want)
-  assert len(calls) == 1                                                          # the first chunk's cross-check only
-  # (3) a closure that ALTERS the predictions must not be short-circuited
+  got_opaque = rollout.chunked_prediction(fn, None, inputs, template, forcings)
+  assert len(calls) == n_steps
+  for k in got_opaque.keys():
+    assert _rel(got_opaque[k].values, want[k].values) < 2e-5
+  #     ... rollout.fuse(fn) is the caller's opt-in: found, cross-checked on the FIRST and the LAST chunk, fused between
+  calls.clear()
+  _equal_datasets(rollout.chunked_prediction(rollout.fuse(fn), None, inputs, template, forcings), want)
+  assert len(calls) == 2
+  assert rollout.last_fused_stats["verify"] and rollout.last_fused_stats["stats"]["cross_check_s"] > 0
+  #     ... and so is GCAST_ROLLOUT_FUSED=closures for every closure of the process (round 5's behaviour)
+  calls.clear()
+  os.environ["GCAST_ROLLOUT_FUSED"] = "closures"
+  try:
+    _equal_datasets(rollout.chunked_prediction(fn, None, inputs, template, forcings), want)
+  finally:
+    del os.environ["GCAST_ROLLOUT_FUSED"]
+  assert len(calls) == 2
+  # (3) an opted-in closure that ALTERS the predictions is not short-circuited: the first chunk's cross-check catches it,
+  #     its own first chunk is what is yielded (it is not called twice for one chunk)
   calls.clear()
   def doubled(rng, inputs, targets_template, forcings):
     calls.append(1)
     out = stack(inputs, targets_template, forcings)
     return xarray.Dataset({k: out[k] * np.float32(2.0) for k in out.keys()}, coords=dict(out._coords))
-  with generic_loop():
-    want2 = rollout.chunked_prediction(doubled, None, inputs, template, forcings)
-  calls.clear()
-  got2 = rollout.chunked_prediction(doubled, None, inputs, template, forcings)
+  want2 = rollout.chunked_prediction(doubled, None, inputs, template, forcings)       # (opaque: the generic loop)
   assert len(calls) == n_steps
-  _equal_datasets(got2, want2)
+  calls.clear()
+  got2 = rollout.chunked_prediction(rollout.fuse(doubled), None, inputs, template, forcings)
+  assert len(calls) == n_steps
+  for k in got2.keys():
+    assert got2[k].dims == want2[k].dims and _rel(got2[k].values, want2[k].values) < 2e-5
+  assert all(isinstance(got2[k].data, np.ndarray) for k in got2.keys())           # host in -> host out on this path too
+  # (3b) ... and one whose extra work only bites LATE (here: from the third chunk on) passes the first cross-check and is
+  #     caught by the last one: RuntimeError, not a silently different trajectory
+  calls.clear()
+  def late(rng, inputs, targets_template, forcings):
+    calls.append(1)
+    out = stack(inputs, targets_template, forcings)
+    if len(calls) < 2:
+      return out
+    return xarray.Dataset({k: out[k] * np.float32(1.5) for k in out.keys()}, coords=dict(out._coords))
+  with pytest.raises(RuntimeError, match="disagrees on the last"):
+    rollout.chunked_prediction(rollout.fuse(late), None, inputs, template, forcings)
+  # (3c) several steps per chunk over a ONE-step stack are not fused (the generic path hands the predictor a multi-time
+  #     template -- only autoregressive.Predictor chunks several steps): both ways take the same path
+  w3 = rollout.chunked_prediction(fn, None, inputs, template, forcings, num_steps_per_chunk=2)
+  g3 = rollout.chunked_prediction(rollout.as_predictor_fn(stack), None, inputs, template, forcings, num_steps_per_chunk=2)
+  _equal_datasets(g3, w3)
   # (4) the reference's full chain with the autoregressive wrapper outermost, two steps per chunk: time-leading
   #     variables, as that wrapper returns them
   ar = autoregressive.Predictor(stack)
@@ -339,11 +375,18 @@ def test_chunked_prediction_runs_the_fused_device_loop_under_a_recognised_stack(
   assert len(chunks) == n_steps and all(c["temperature"].data.is_cuda for c in chunks)
   for s, c in enumerate(chunks):
     np.testing.assert_array_equal(c["temperature"].values, want["temperature"].isel(time=slice(s, s + 1)).values)
-  # (6) the switch
+  # (6) the switch: GCAST_ROLLOUT_FUSED=0 fuses nobody, opted in or not
   with generic_loop():
     calls.clear()
-    rollout.chunked_prediction(fn, None, inputs, template, forcings)
+    rollout.chunked_prediction(rollout.fuse(fn), None, inputs, template, forcings)
     assert len(calls) == n_steps
+  # (7) a consumer that stops after the first chunk still hears of an out-of-range input state (the range
+  #     flag used to be read only when the generator was exhausted)
+  from graphcast_amd import _native as nat
+  huge = xarray.Dataset({k: inputs[k] * np.float32(3e6) for k in inputs.keys()}, coords=dict(inputs._coords))
+  gen = rollout.chunked_prediction_generator(rollout.as_predictor_fn(stack), None, huge, template, 1, forcings)
+  with pytest.raises(nat.GcastRangeError):
+    next(gen)
 
 
 def test_fused_rollout_in_the_bfloat16_tier(setup):
@@ -358,6 +401,6 @@ def test_fused_rollout_in_the_bfloat16_tier(setup):
   with casting.precision_view(model, "bf16"):
     roll = rollout_device.DeviceRollout(model, std, mean, dstd)
     want = roll.to_dataset(roll.run(inputs, template, forcings), template)
-  got = rollout.chunked_prediction(lambda rng, **kw: stack(**kw), None, inputs, template, forcings)     # (cross-checked)
+  got = rollout.chunked_prediction(rollout.fuse(lambda rng, **kw: stack(**kw)), None, inputs, template, forcings)     # (cross-checked)
   assert model._precision is None
   _equal_datasets(got, want)
