@@ -259,6 +259,11 @@ def main():
                   help="N = 1: additionally (outside the timed region) time an autoregressive rollout of this many 6-h "
                        "steps with the state resident in HBM -- BASELINE.json config 3: 40 = ten days -- and report it "
                        "as `rollout` in the line; 0 = skip")
+  ap.add_argument("--single-process", action="store_true",
+                  help="the SECOND launch form of --gpus N (round 6): ONE process drives N engines, one per device -- the "
+                       "reference's pmap_devices form (utils/rollout.py:196-283; rollout.chunked_prediction_generator("
+                       "pmap_devices=...) here) -- instead of one process per GPU.  Devices are cuda:0 .. cuda:N-1, wrapping "
+                       "around the visible ones (a 1-GPU box runs N engines on N streams of its one device)")
   args = ap.parse_args()
 
   # stdout carries ONE JSON line and nothing else.  RCCL prints a version banner to the C-level stdout of every process
@@ -279,6 +284,10 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
+  if args.single_process:
+    if world != 1:
+      raise SystemExit("--single-process is ONE process driving --gpus N devices: launch it without torch.distributed.run")
+    return single_process_main(args)
   if world != args.gpus:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
                      "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
@@ -653,6 +662,100 @@ def rollout_api_extra(model, task, lat, lon, n_steps):
                   "(fused device loop); ms_per_step_fused_closure: rollout.fuse(closure) -- the caller's opt-in, + first- and "
                   "last-chunk cross-checks; generic_loop_ms_per_step: the plain closure, opaque as in the reference (called for "
                   "every chunk; the default for closures since round 6); parity: tests/test_rollout_gpu.py (bitwise = DeviceRollout)"}
+
+
+def single_process_main(args):
+  """`bench.py --gpus N --single-process`: ensemble member d on device d, all N engines driven from THIS process (the
+  pmap_devices form: `GraphCast.replica` per device -- shared parameters and graphs, own plan + workspace -- one stream
+  each; per step the launches of every device are enqueued before the host waits on any).  Same contract: K timed steps
+  per device bracketed by a synchronisation of every device, `value` = N x K / elapsed.  Unmeasured at N > 1 DEVICES
+  until a multi-GPU node exists: on a 1-GPU box the N engines share the one device (then `value` is that device's rate,
+  not a scaling point -- `config.devices` says which it was)."""
+  import torch
+  from graphcast_amd import _native as nat
+  from graphcast_amd import graphcast as gc
+  res, mesh_size, levels, gnn_steps = CONFIGS[args.config]
+  task = {37: gc.TASK, 13: gc.TASK_13}[levels]
+  c_out = gc.num_output_channels(task)
+  c_in = 2 * (5 + 6 * levels) + 2 * 5 + 2 + 5
+  lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=LATENT, gnn_msg_steps=gnn_steps, hidden_layers=1,
+                       radius_query_fraction_edge_length=0.6)
+  visible = torch.cuda.device_count()
+  devices = [f"cuda:{d % visible}" for d in range(args.gpus)]
+  t_setup = time.perf_counter()
+  params = fast_params(c_in, c_out, gnn_steps)
+  model = gc.GraphCast(cfg, task, params=params, device=devices[0], precision=args.precision)
+  model.init_from_coordinates(lat, lon)
+  g = model.graph_arrays()
+  members = []
+  for d, dev in enumerate(devices):
+    m = model if d == 0 else model.replica(dev)
+    with torch.cuda.device(dev):
+      stream = torch.cuda.Stream(device=dev)
+      x = torch.from_numpy(np.random.default_rng(d).standard_normal((g["n_grid"], 1, c_in), dtype=np.float32)).to(dev)
+      y = torch.empty((g["n_grid"], 1, c_out), dtype=torch.float32, device=dev)
+      with torch.cuda.stream(stream):
+        m.forward_grid_node_features(x, y)        # builds the replica's engine + folds its constants
+    members.append((m, stream, x, y, dev))
+
+  def sync_all():
+    for dev in sorted(set(devices)):
+      torch.cuda.synchronize(dev)
+
+  def step_all():
+    for m, stream, x, y, dev in members:          # every device's launches are enqueued before the host waits on any
+      with torch.cuda.device(dev), torch.cuda.stream(stream):
+        m._engine(x, y)
+
+  sync_all()
+  t_setup = time.perf_counter() - t_setup
+  for _ in range(args.warmup):
+    step_all()
+  sync_all()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step_all()
+  sync_all()
+  elapsed = time.perf_counter() - t0
+  for m, *_ in members:
+    m._engine.check_range()
+  finite = all(bool(torch.isfinite(y).all().item()) for _, _, _, y, _ in members)
+  same_bits = None
+  if len(set(devices)) < len(devices):            # engines sharing a device: a member re-run ALONE gives the same bits
+    m, stream, x, y, dev = members[-1]
+    alone = torch.empty_like(y)
+    m._engine(x, alone)
+    torch.cuda.synchronize(dev)
+    same_bits = bool(torch.equal(alone, y))
+  engine = model._engine
+  precision = engine.precision
+  peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
+  per_stage = stage_table(engine, members[0][2], members[0][3], args.op_timing_iters)
+  dominant = max(per_stage, key=lambda k: per_stage[k]["ms"])
+  dom = per_stage[dominant]
+  achieved = dom["tflop"] / (dom["ms"] / 1e3) if dom["ms"] > 0 else 0.0
+  line = {
+      "metric": "6-h rollout steps/sec at 0.25deg/37-level", "value": args.gpus * args.steps / elapsed, "unit": "steps/s",
+      "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": {"f16x3": "f32 (3 x f16-split MFMA products, f32 accumulate)", "f32": "f32",
+                "bf16": "bf16 activations + parameters, f32 accumulate (reduced-precision TIER)"}[precision],
+      "data": "synthetic",
+      "config": {"workload": f"GraphCast {args.config}: one encode-process-decode 6-h step per ensemble member",
+                 "parallelism": f"ensemble x{args.gpus}, ONE process driving {args.gpus} engines (the reference's pmap_devices "
+                                "form; no collective in the step)",
+                 "devices": devices, "distinct_devices": len(set(devices)), "batch_per_gpu": 1,
+                 "note": (None if len(set(devices)) == len(devices) else
+                          "engines share a device: `value` is that device's rate with several engines resident, not a scaling point")},
+      "roofline": {"bound": "mfma", "kernel": f"rowmlp16h_kernel<MLP_LN> stage {dominant} (engine 0, timed alone)",
+                   "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                   "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                   "stages": stages_summary(per_stage, peak)},
+      "cpu_baseline": None,
+      "precision": precision, "output_finite": finite, "member_alone_gives_the_same_bits": same_bits,
+      "setup_seconds": round(t_setup, 1), "build": nat.lib().gc_build_info().decode(), "tuning": nat.tuning_string()}
+  emit_line(json.dumps(line))
 
 
 def partition_main(args, rank, world, device, distributed):

@@ -157,6 +157,19 @@ class GraphCast(predictor_base.Predictor):
       self._precision = precision
     return prev
 
+  def replica(self, device) -> "GraphCast":
+    """The same model on another device -- or a second, independent instance on the same one: configuration, parameters
+    and the static graphs (numpy, read-only) are SHARED, the engine (packed weights, plan, workspace: what lives on the
+    device) is the replica's own.  What ``rollout.chunked_prediction_generator(..., pmap_devices=[...])`` places on every
+    listed device: one process driving several GPUs, the reference's ``pmap`` over ``sample``
+    (``utils/rollout.py:196-283``)."""
+    import copy
+    other = copy.copy(self)
+    other._device = str(device)
+    other._engine = None
+    other._engines = {}
+    return other
+
   def check_range(self) -> None:
     """Blocks until the steps enqueued so far are done and raises ``GcastRangeError`` if one of them read a value
     outside the exact range of the f16x3 arithmetic.  ``__call__`` on device-resident Datasets only SCHEDULES that

@@ -269,9 +269,12 @@ def _agree(fused, generic, tol) -> bool:
 class _FusedLoop:
   """``rollout_device.DeviceRollout``'s step loop, chunk by chunk, presenting what the recognised stack would return."""
 
-  def __init__(self, stack: _Stack, schedule: "_ChunkSchedule", staged_inputs, keep_device: int = 0):
+  def __init__(self, stack: _Stack, schedule: "_ChunkSchedule", staged_inputs, keep_device: int = 0, stream=None):
     from graphcast_amd import rollout_device
     self.stack, self.schedule = stack, schedule
+    # (`stream`: the torch stream this loop enqueues on -- one per member of a pmap_devices group, so that several loops
+    #  of ONE process run side by side, on several devices or on one; None = the device's current stream)
+    self.stream = stream
     # (an opted-in closure's last-chunk cross-check rebuilds that chunk's input window ON THE DEVICE: the step outputs of
     #  the `keep_device` most recent chunks stay referenced -- 0.94 GB each at 0.25 deg, HBM has room)
     self.keep_device, self.recent = keep_device, []
@@ -280,10 +283,20 @@ class _FusedLoop:
     self.stats = {"prepare_s": 0.0, "enqueue_s": 0.0, "pinned_alloc_s": 0.0, "copy_issue_s": 0.0, "wait_copy_s": 0.0,
                   "dataset_s": 0.0}            # host seconds by phase (bench.py: rollout_api.host_seconds)
     t0 = time.perf_counter()
-    with self._view_once():
+    with self._on_stream(), self._view_once():
       self.steps = self.roll.steps(staged_inputs, schedule.template, schedule.forcings)
       self._first = next(self.steps)             # (runs _prepare: raises HERE if the stack cannot take these datasets)
     self.stats["prepare_s"] = time.perf_counter() - t0
+
+  def _on_stream(self):
+    import contextlib
+    import torch
+    if self.stream is None:
+      return contextlib.nullcontext()
+    ctx = contextlib.ExitStack()
+    ctx.enter_context(torch.cuda.device(self.stream.device))
+    ctx.enter_context(torch.cuda.stream(self.stream))
+    return ctx
 
   @staticmethod
   def _nothing():
@@ -300,15 +313,16 @@ class _FusedLoop:
     import torch
     return torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
 
-  def start(self, k, template_k, host):
+  def start(self, k, template_k, host, host_out=None):
     """Enqueues the steps of chunk k; ``host``: also their device -> host copies (ONE contiguous copy of each step's
     ``[N_grid, B, C_out]`` block into pinned pages, on a side stream behind an event, so that it runs under the NEXT
-    chunk's steps).  Returns a handle for ``finish``."""
+    chunk's steps; ``host_out``: the pinned destination of every step, given by the caller -- a member's slice of a
+    group's stacked buffer).  Returns a handle for ``finish``."""
     import torch
     n = self.schedule.steps_per_chunk
     dev = torch.device(self.stack.model._device)
     parts = []
-    with self._view_once():
+    with self._on_stream(), self._view_once():
       for j in range(n):
         t0 = time.perf_counter()
         s, pred = self._first if self._first is not None else next(self.steps)
@@ -321,7 +335,7 @@ class _FusedLoop:
             self._side = torch.cuda.Stream(device=dev)
           ready = torch.cuda.Event()
           ready.record(torch.cuda.current_stream(dev))
-          y_host = self._pinned(pred)
+          y_host = host_out[j] if host_out is not None else self._pinned(pred)
           t2 = time.perf_counter()
           self.stats["pinned_alloc_s"] += t2 - t1
           flag = getattr(self.stack.model._engine, "range_flag", None)      # (the f16x3 arithmetic's range word, or None)
@@ -448,6 +462,162 @@ class _ChunkSchedule:
     return predictions
 
 
+# ----------------------------------------------------------------------------- pmap_devices
+def replicate_dataset(data: Optional[xarray.Dataset], replica_dim: str, replicate_to_device: bool = False,
+                      devices: Optional[Sequence[Any]] = None, num_replicas: Optional[int] = None):
+  """A leading ``replica_dim`` axis on every variable that does not have one (reference :89-155: "used to prepare for
+  xarray_jax.pmap").  Here the replicas are zero-stride views (nothing of the replicated size is allocated) and
+  ``replicate_to_device`` places nothing: every member of a ``pmap_devices`` group is uploaded to ITS device by the
+  rollout itself."""
+  if devices is not None and num_replicas is not None:
+    if len(devices) != num_replicas:
+      raise ValueError(f"devices: {len(devices)} != replicas: {num_replicas}")
+  elif devices is not None:
+    num_replicas = len(devices)
+  elif num_replicas is None:
+    raise ValueError("num_replicas must be specified.")
+  elif replicate_to_device:
+    raise ValueError("devices must be specified when replicate_to_device is True.")
+  if data is None:
+    return None
+
+  def replicate_variable(v: xarray.Variable) -> xarray.Variable:
+    if replica_dim in v.dims:
+      if v.sizes[replica_dim] != num_replicas:
+        raise ValueError(f"Variable {v} has {v.sizes[replica_dim]} replicas, but {num_replicas} were requested.")
+      return v.transpose(replica_dim, ...)
+    shape = (num_replicas,) + tuple(v.shape)
+    if xarray._is_torch(v.data):
+      return xarray.Variable((replica_dim,) + tuple(v.dims), v.data.unsqueeze(0).expand(*shape))
+    return xarray.Variable((replica_dim,) + tuple(v.dims), np.broadcast_to(np.asarray(v.data)[None], shape))
+
+  return xarray.Dataset._construct({k: replicate_variable(v) for k, v in data._vars.items()}, dict(data._coords))
+
+
+def _pmap_device_list(pmap_devices):
+  """``pmap_devices`` as (torch.device, ordinal among equal entries): "cuda:1", 1, torch.device -- the same device may
+  be listed more than once (several independent engines on one GPU, each on its own stream)."""
+  import torch
+  out, seen = [], {}
+  for d in pmap_devices:
+    dev = torch.device(f"cuda:{d}" if isinstance(d, (int, np.integer)) else d)
+    if dev.type == "cuda" and dev.index is None:
+      dev = torch.device("cuda", torch.cuda.current_device())
+    n = seen.get(str(dev), 0)
+    seen[str(dev)] = n + 1
+    out.append((dev, n))
+  return out
+
+
+def _model_replica(model, dev, ordinal):
+  """The stack's model on (device, ordinal): the model itself for the first entry naming its own device, a cached
+  ``GraphCast.replica`` (shared parameters and graphs, own engine) otherwise."""
+  import torch
+  own = torch.device(model._device)
+  if own.type == "cuda" and own.index is None:
+    own = torch.device("cuda", torch.cuda.current_device())
+  if ordinal == 0 and own == dev:
+    return model
+  cache = model.__dict__.setdefault("_pmap_replicas", {})
+  key = (str(dev), ordinal)
+  if key not in cache or cache[key]._params is not model._params:
+    cache[key] = model.replica(dev)
+  cache[key]._precision = model._precision
+  return cache[key]
+
+
+def _with_replica_dim(ds, replica_dim, n):
+  return replicate_dataset(ds, replica_dim, num_replicas=n)
+
+
+def _pmap_rollout(predictor_fn, rngs, member_inputs, targets_template, member_forcings, num_steps_per_chunk, devices,
+                  replica_axis, verbose, rng_split_fn):
+  """One group of ``len(devices)`` rollouts driven side by side from THIS process -- the reference's pmapped branch
+  (utils/rollout.py:196-283, :471-487): every chunk is yielded ONCE, its variables stacked along a leading
+  ``replica_axis`` (member d of the group on ``devices[d]``).
+
+  Under ``as_predictor_fn(stack)`` of a recognisable stack every listed device gets its own engine (``GraphCast.replica``:
+  shared parameters and graphs) and its own fused device loop on its own stream; per chunk the steps of ALL devices are
+  enqueued before the host waits for any of them, and every device copies its ``[N_grid, B, C_out]`` blocks into its slice
+  of ONE pinned ``[members, N_grid, B, C_out]`` buffer per step (the yielded variables are numpy views of it: host
+  Datasets -- a torch tensor cannot span devices the way a sharded jax array does).  Any other ``predictor_fn`` is an
+  opaque callable bound to whatever device it closes over: the members are then stepped one after another through it,
+  chunk by chunk, and stacked -- same results, no parallelism."""
+  D = len(devices)
+  schedules = [_ChunkSchedule(member_inputs[d], targets_template, member_forcings[d], num_steps_per_chunk) for d in range(D)]
+  sched0 = schedules[0]
+  identity = lambda ds: ds
+  stack = _fused_stack(predictor_fn)
+  if stack is not None and (stack.verify or not (num_steps_per_chunk == 1 or stack.time_leading)):
+    stack = None
+  if stack is None:
+    # ---- opaque predictor_fn: D generic rollouts advanced in lockstep
+    gens = [chunked_prediction_generator(predictor_fn, rngs[d], member_inputs[d], targets_template, num_steps_per_chunk,
+                                         member_forcings[d], verbose=verbose, rng_split_fn=rng_split_fn) for d in range(D)]
+    for _ in range(sched0.num_chunks):
+      chunks = [xarray.to_host(next(g)) for g in gens]
+      yield xarray.concat(chunks, dim=replica_axis)
+    for g in gens:
+      for _ in g:                               # (exhausts the generators: their end-of-rollout range checks run)
+        pass
+    return
+  # ---- one fused loop per listed device
+  import torch
+  model = stack.model
+  lat, lon = np.asarray(sched0.first_inputs.coords["lat"].values), np.asarray(sched0.first_inputs.coords["lon"].values)
+  model._maybe_init(lat, lon)                   # (once: the replicas share the static graphs)
+  loops = []
+  for d, (dev, ordinal) in enumerate(devices):
+    replica = _model_replica(model, dev, ordinal)
+    st = _Stack(replica, stack.std, stack.mean, stack.dstd, stack.tier, stack.time_leading, False)
+    with torch.cuda.device(dev):
+      stream = torch.cuda.Stream(device=dev)
+    staged = xarray.to_device(schedules[d].first_inputs, str(dev))
+    loops.append(_FusedLoop(st, schedules[d], staged, stream=stream))
+  last_fused_stats.clear()
+  last_fused_stats.update(verify=False, pmap_devices=[str(dev) for dev, _ in devices], stats=loops[0].stats)
+  rngs = list(rngs)
+  pending = None
+
+  def finish(done):
+    handles, ys, template_k, k_done, coords_done = done
+    for loop, handle in zip(loops, handles):
+      loop.finish(handle)                       # (waits for this member's copies; raises GcastRangeError on its flag)
+    per_step = []
+    for j, y in enumerate(ys):
+      tmpl = _with_replica_dim(template_k.isel(time=slice(j, j + 1)), replica_axis, D)
+      a = y.numpy()
+      grid = (len(lat), len(lon))
+      leading = xarray.DataArray(a.reshape((D,) + grid + tuple(a.shape[2:])),
+                                 dims=(replica_axis, "lat", "lon", "batch", "channels"))
+      from graphcast_amd import model_utils
+      restored = leading.transpose(replica_axis, "batch", "lat", "lon", "channels")
+      per_step.append(model_utils.stacked_to_dataset(restored.variable, tmpl))
+    out = per_step[0] if len(per_step) == 1 else xarray.concat(per_step, dim="time")
+    if stack.time_leading:                      # autoregressive.Predictor: (time, batch, ...) per member
+      out = xarray.Dataset._construct({name: v.transpose(replica_axis, "time", ...) for name, v in out._vars.items()},
+                                      out._coords)
+    out = out.assign_coords({name: v.variable for name, v in template_k.coords.items() if "time" in v.dims})
+    return sched0.stamp(out, k_done, coords_done)
+
+  for k in range(sched0.num_chunks):
+    if verbose:
+      log.info("Chunk %d/%d", k, sched0.num_chunks)
+    template_k, _, true_coords = sched0.chunk(k, identity)
+    for d in range(D):
+      rngs[d], _ = split_rng(rngs[d], rng_split_fn)
+    # phase A: chunk k enqueued on EVERY device (steps + the copies into the group's stacked pinned buffers) ...
+    shape = (D,) + tuple(loops[0].roll._last_advance[4].shape)
+    ys = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(num_steps_per_chunk)]
+    handles = [loops[d].start(k, template_k, True, host_out=[y[d] for y in ys]) for d in range(D)]
+    # ... phase B: only then does the host wait -- for the PREVIOUS chunk, whose copies ran under this chunk's steps
+    if pending is not None:
+      yield finish(pending)
+    pending = (handles, ys, template_k, k, true_coords)
+  if pending is not None:
+    yield finish(pending)
+
+
 def chunked_prediction_generator(
     predictor_fn: PredictorFn,
     rng: Any,
@@ -466,12 +636,35 @@ def chunked_prediction_generator(
 
   ``rng_split_fn`` (not in the reference): how to split an rng key this module does not know
   (see ``split_rng``)."""
-  if pmap_devices is not None:
-    raise ValueError(
-        "pmap_devices is a single-process multi-device feature of the reference; this build runs "
-        "one process per GPU: use chunked_prediction_generator_multiple_runs(rank=, world_size=).")
+  if pmap_devices is not None and replica_axis is None:
+    raise ValueError("Must provide replica_axis when pmap_devices is provided.")
   if (replicate_fn is None) ^ (replica_axis is None):
     raise ValueError("Must provide replicate_fn when replica_axis is provided.")
+  if pmap_devices is not None:
+    # The reference's single-process multi-device rollout (:196-283, :471-487): there `predictor_fn` is pmapped over
+    # `pmap_devices` and the Datasets carry a `replica_axis` of that length.  Here: one engine per listed device driven
+    # from this process (_pmap_rollout); `rng` may be a sequence of len(pmap_devices) keys; `device_put_fn` places
+    # nothing (every member is uploaded to its own device).
+    devices = _pmap_device_list(pmap_devices)
+    D = len(devices)
+    inputs, targets_template, forcings = (xarray.from_xarray(inputs), xarray.from_xarray(targets_template),
+                                          xarray.from_xarray(forcings))
+    if replica_axis not in inputs.dims:
+      inputs = replicate_fn(inputs)
+    if inputs.sizes.get(replica_axis) != D:
+      raise ValueError(f"inputs have {inputs.sizes.get(replica_axis)} replicas along {replica_axis!r}, "
+                       f"pmap_devices lists {D} devices")
+    if replica_axis in targets_template.dims:
+      targets_template = targets_template.isel({replica_axis: 0}, drop=True)
+    member = lambda ds, d: ds if ds is None or replica_axis not in ds.dims else ds.isel({replica_axis: d}, drop=True)
+    rngs = (list(rng) if isinstance(rng, (list, tuple)) or (isinstance(rng, np.ndarray) and rng.ndim >= 1 and len(rng) == D)
+            else [rng] * D)
+    if len(rngs) != D:
+      raise ValueError(f"{len(rngs)} rng keys for {D} pmap_devices")
+    yield from _pmap_rollout(predictor_fn, rngs, [member(inputs, d) for d in range(D)], targets_template,
+                             [member(forcings, d) for d in range(D)], num_steps_per_chunk, devices, replica_axis, verbose,
+                             rng_split_fn)
+    return
 
   def stage(ds):
     if replicate_fn is not None:
@@ -648,10 +841,11 @@ def chunked_prediction_generator_multiple_runs(
   un-pmapped branch (:286-307).  With ``world_size`` > 1 (one process per GPU) this rank
   only rolls out members ``rank, rank + world_size, ...``: members never interact, so
   there is no collective (``ensemble.gather_member_chunks`` collects results if wanted).
+
+  ``pmap_devices`` (round 6; the reference's pmapped branch, :228-283): groups of ``len(pmap_devices)`` members, one per
+  listed device, rolled out side by side from THIS process; every chunk carries the group stacked along ``sample`` with
+  ``sample`` = the members' indices.  See ``_pmap_rollout`` for what runs on each device.
   """
-  if pmap_devices is not None:
-    raise ValueError("pmap_devices is not supported: launch one process per GPU and pass "
-                     "rank= / world_size= instead.")
   if num_samples is None:
     if "sample" not in inputs.dims:
       raise ValueError(
@@ -670,6 +864,27 @@ def chunked_prediction_generator_multiple_runs(
           f"{forcings.sizes['sample']}.")
   if not 0 <= rank < world_size:
     raise ValueError(f"rank {rank} outside world of size {world_size}")
+
+  if pmap_devices is not None:
+    # The reference's pmapped branch (:228-283): groups of len(pmap_devices) members, one per device, driven from ONE
+    # process; every chunk carries the group's members stacked along "sample" and the coordinate sample = their indices.
+    # (With world_size > 1 the groups are dealt round-robin to the ranks: each rank drives its own pmap_devices.)
+    per_chunk = len(pmap_devices)
+    if num_samples % per_chunk != 0:
+      raise ValueError(f"{num_samples} must multiple of {per_chunk}")
+    replicate_fn = functools.partial(replicate_dataset, replica_dim="sample", devices=None, num_replicas=per_chunk,
+                                     replicate_to_device=False)
+    groups = list(range(0, num_samples, per_chunk))
+    for i in groups[rank::world_size]:
+      idx = slice(i, i + per_chunk)
+      log.info("Samples (%s, %s) out of %s", idx.start, idx.stop, num_samples)
+      sample_inputs, sample_forcings = _slice_sample_if_present(inputs, forcings, idx)
+      for prediction_chunk in chunked_prediction_generator(
+          predictor_fn, list(rngs[idx]), inputs=sample_inputs, targets_template=targets_template, forcings=sample_forcings,
+          pmap_devices=pmap_devices, replica_axis="sample", replicate_fn=replicate_fn, **chunked_prediction_kwargs):
+        prediction_chunk.coords["sample"] = xarray.Variable(("sample",), np.arange(idx.start, idx.stop))
+        yield prediction_chunk
+    return
 
   for i in range(rank, num_samples, world_size):
     log.info("Sample %d/%d", i, num_samples)
