@@ -111,6 +111,8 @@ class StepEngine(launch.LaunchBase):
     # workgroup per CU (0 = never); the attribute lets a caller (smoke(), tests) change it per engine.
     self.wide_min_rows = None      # (None: the plan's choice.  An int: two-pass MLP launches without gather / segment-sum
     #                                 from that many rows on run in the wide form -- smoke(), tests)
+    self.wide_edges = 0            # (bit 0: every one-pass edge update, bit 1: every two-pass one, in the wide form WHATEVER
+    #                                 its size -- smoke(), tests; 0: the library's rule, gc_tuning.wide_edges)
     self.n_grid, self.n_mesh = int(graphs["n_grid"]), int(graphs["n_mesh"])
     self.c_in, self.c_out, self.num_steps = c_in, c_out, num_steps
     if c_out > 240:
@@ -210,6 +212,12 @@ class StepEngine(launch.LaunchBase):
             m.flags |= nat.WG_WIDE
           elif self.helpers_min_rows and m.n_rows >= self.helpers_min_rows:
             m.flags |= nat.WG_HELPERS
+    if self.wide_edges:
+      for k in range(n.value):
+        m = ops[k].mlp
+        if (ops[k].kind == nat.OP_ROWMLP and m.layout == nat.LAYOUT_HALF and m.prec == nat.PREC_F16X3 and m.seg
+            and m.mode == nat.MODE_MLP_LN and (self.wide_edges & (1 if m.flags & nat.W2_NATURAL else 2))):
+          m.flags = (m.flags & ~(nat.WG_HELPERS | nat.WG_NO_HELPERS)) | nat.WG_WIDE
     return ops, y
 
   def _clear_tile_queue(self):

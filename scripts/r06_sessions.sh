@@ -29,5 +29,16 @@ case "$NAME" in
     bash scripts/session.sh bench-ab r06_s1 "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_WIDE_EDGES=2" "GCAST_WIDE_EDGES=3" \
         "GCAST_LIB_PATH=ab_libs/libgcast_wpark0.so" "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_LIB_PATH=ab_libs/libgcast_wpark0.so"
     ;;
+  s2)
+    # Round-6 session 2: the host-side changes on the GPU -- the fused rollout as an opt-in (as_predictor_fn / fuse, first +
+    # last chunk cross-checks on device-resident Datasets), pmap_devices (two engines on one GPU), per-plan tuning, the
+    # plan against the reference-executed fixture; then the bench line with value_rollout / rollout_api, the
+    # single-process launch form, and more same-session samples of gc_tuning.wide_edges.
+    timeout 1500 python -m pytest tests/test_native_abi.py tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -5 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "host-side changes"
+    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench.json"
+    timeout 900 python bench.py --gpus 2 --single-process --steps 10 --warmup 3 > "$OUT/bench_single_process_2.json" 2> "$OUT/bench_single_process_2.err"; echo "single-process rc=$?"; show "$OUT/bench_single_process_2.json"
+    bash scripts/session.sh bench-ab r06_s2 "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_WIDE_EDGES=3" "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_WIDE_EDGES=3"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

@@ -102,6 +102,20 @@ def test_step_gives_the_same_bits_in_the_one_workgroup_per_cu_forms(small):
     marked = [ops[k].mlp.flags & (nat.WG_WIDE | nat.WG_HELPERS) for k in range(len(ops)) if ops[k].kind == nat.OP_ROWMLP]
     assert sum(f == (nat.WG_WIDE if knob == "wide_min_rows" else nat.WG_HELPERS) for f in marked) >= 3, (knob, marked)
     assert torch.equal(y, want), knob
+  # round 6: ... and with EVERY edge update -- the one-pass ones (encoder, decoder, processor step 0) and the two-pass
+  # ones (the other processor steps) -- in the wide form too: segment-sums per 64-row sub-tile, ten of sixteen parked
+  # n-blocks in LDS; together with the node-side launches above the whole step then runs one workgroup per CU
+  m = gc.GraphCast(cfg, gc.TASK_13, params=small["params"], precision="f16x3").init_from_coordinates(lat, lon)
+  e = m._get_engine(small["c_in"])
+  e.wide_edges, e.wide_min_rows = 3, 1
+  y = m.forward_grid_node_features(x)
+  torch.cuda.synchronize()
+  ops, _ = e.bind(x)
+  edge_ops = [ops[k].mlp for k in range(len(ops)) if ops[k].kind == nat.OP_ROWMLP and ops[k].mlp.seg]
+  batch = x.shape[1]                           # (the program runs the batch elements one after another)
+  assert len(edge_ops) == batch * (2 + cfg.gnn_msg_steps) and all(o.flags & nat.WG_WIDE for o in edge_ops)
+  assert sum(bool(o.flags & nat.W2_NATURAL) for o in edge_ops) == batch * 3
+  assert torch.equal(y, want)
 
 
 def test_missing_params_and_bad_shapes_raise(small):
