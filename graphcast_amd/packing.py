@@ -133,7 +133,7 @@ def from_pi(a):
 
 
 def pack_weight_bf16(w, np_cols=LATENT, chained=False):
-  """[K, N] float32 -> uint16 [ceil32(K)/32, np_cols/16, 64, 8]: the GC_PREC_BF16_GEMM layout of
+  """[K, N] float32 -> uint16 [ceil32(K)/32, np_cols/16, 64, 8]: the GC_PREC_BF16_IMAGE layout of
   include/gcast.h (the hi-only analogue of ``pack_weight_split``, same K maps)."""
   w = np.asarray(w, dtype=np.float32)
   k, n = w.shape
