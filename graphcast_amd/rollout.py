@@ -592,7 +592,8 @@ def _pmap_rollout(predictor_fn, rngs, member_inputs, targets_template, member_fo
                                  dims=(replica_axis, "lat", "lon", "batch", "channels"))
       from graphcast_amd import model_utils
       restored = leading.transpose(replica_axis, "batch", "lat", "lon", "channels")
-      per_step.append(model_utils.stacked_to_dataset(restored.variable, tmpl))
+      per_step.append(model_utils.stacked_to_dataset(restored.variable, tmpl,
+                                                     preserved_dims=(replica_axis, "batch", "lat", "lon")))
     out = per_step[0] if len(per_step) == 1 else xarray.concat(per_step, dim="time")
     if stack.time_leading:                      # autoregressive.Predictor: (time, batch, ...) per member
       out = xarray.Dataset._construct({name: v.transpose(replica_axis, "time", ...) for name, v in out._vars.items()},
