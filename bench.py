@@ -82,33 +82,44 @@ def _stamped_profile(name, stage):
   return dict(table[stage], env=(table["_stamp"].get("env") or {})), None
 
 
+def _profile_name(kind, precision_key):
+  """The committed counter summary of an arithmetic: the f16x3 headline and (round 6) the bf16 tier."""
+  if precision_key.startswith("f16x3h"):
+    return f"current_{kind}_by_stage.json"
+  if precision_key.startswith("bf16"):
+    return f"current_{kind}_by_stage_bf16.json"
+  return None
+
+
 def measured_traffic(precision_key, stage):
   """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
   WRITE_SIZE passes of the same bench command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
   keyed to the loaded build (see _stamped_profile)."""
-  if not precision_key.startswith("f16x3h"):
+  name = _profile_name("pmc", precision_key)
+  if name is None:
     return None, "no counter profile is kept for this arithmetic / formulation"
-  st, why = _stamped_profile("current_pmc_by_stage.json", stage)
+  st, why = _stamped_profile(name, stage)
   if st is None:
     return None, why
   return {"bytes_per_launch": st["traffic_bytes_per_launch"], "fetch_bytes_per_launch": st["fetch_bytes_per_launch"],
           "write_bytes_per_launch": st["write_bytes_per_launch"], "algorithmic_bytes": st["algorithmic_bytes_per_launch"],
           "traffic_over_algorithmic": st["traffic_over_algorithmic"],
-          "source": "profiles/current_pmc_by_stage.json (scripts/pmc_by_stage.py; L2 <-> fabric boundary: Infinity-Cache hits "
+          "source": f"profiles/{name} (scripts/pmc_by_stage.py; L2 <-> fabric boundary: Infinity-Cache hits "
                     "are counted)", "env": st["env"]}, None
 
 
 def measured_mfma_busy(precision_key, stage):
   """MFMA pipe busy fraction (and wave wait fractions) of the dominant launch from the committed rocprofv3 SQ counter
   passes of the SAME command, keyed to the loaded build (see _stamped_profile)."""
-  if not precision_key.startswith("f16x3h"):
+  name = _profile_name("sq", precision_key)
+  if name is None:
     return None, "no counter profile is kept for this arithmetic / formulation"
-  st, why = _stamped_profile("current_sq_by_stage.json", stage)
+  st, why = _stamped_profile(name, stage)
   if st is None:
     return None, why
   return {"mfma_busy_per_simd": st.get("mfma_busy_per_simd"), "wave_waiting": st.get("wave_waiting"),
           "lds_bank_conflict": st.get("lds_bank_conflict"),
-          "source": "profiles/current_sq_by_stage.json (scripts/sq_by_stage.py)", "env": st["env"]}, None
+          "source": f"profiles/{name} (scripts/sq_by_stage.py)", "env": st["env"]}, None
 
 
 def fast_params(c_in, c_out, steps, seed=1):

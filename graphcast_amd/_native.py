@@ -26,7 +26,7 @@ TILE_MAP_XCD = 16                                 # GC_TILE_XCD
 TILE_QUEUE_ANY = 128                              # GC_TILE_QUEUE_ANY: the dynamic tile queue whenever a launch has a second round
 WG_HELPERS, WG_NO_HELPERS = 32, 64                # GC_WG_HELPERS / GC_WG_NO_HELPERS (eight-wave form of a GC_LAYOUT_HALF launch)
 WG_WIDE = 256                                     # GC_WG_WIDE (eight MULTIPLYING waves per CU on one weight ring; round 6: segment-sum / one-pass launches too)
-WIDE_EDGES_DEFAULT = 0                            # GC_WIDE_EDGES_DEFAULT (gc_tuning.wide_edges of a process without GCAST_WIDE_EDGES)
+WIDE_EDGES_DEFAULT = 3                            # GC_WIDE_EDGES_DEFAULT (gc_tuning.wide_edges of a process without GCAST_WIDE_EDGES)
 TILE_ROWS = 64
 K_CHUNK = 32
 SCRATCH_SLOTS = 512                               # GC_SCRATCH_SLOTS: persistent workgroups of a GC_LAYOUT_HALF launch

@@ -512,7 +512,7 @@ int gc_plan_get_tuning(const gc_plan* plan, gc_tuning* out);
 const char* gc_tuning_string(const gc_tuning* t);
 #define GC_WIDE_EDGE_MIN_TILES 4096   /* 64-row tiles: >= 8 rounds of 256 wide tiles */
 #ifndef GC_WIDE_EDGES_DEFAULT
-#define GC_WIDE_EDGES_DEFAULT 0       /* gc_tuning.wide_edges of a process that does not set GCAST_WIDE_EDGES */
+#define GC_WIDE_EDGES_DEFAULT 3       /* gc_tuning.wide_edges of a process that does not set GCAST_WIDE_EDGES */
 #endif
 
 /* sizeof(gc_rowmlp_desc) for what == 0, sizeof(gc_op) for 1, sizeof(gc_advance_desc) for 2, sizeof(gc_model_desc) for 3, sizeof(gc_tuning) for 4, 0 otherwise:

@@ -40,5 +40,15 @@ case "$NAME" in
     timeout 900 python bench.py --gpus 2 --single-process --steps 10 --warmup 3 > "$OUT/bench_single_process_2.json" 2> "$OUT/bench_single_process_2.err"; echo "single-process rc=$?"; show "$OUT/bench_single_process_2.json"
     bash scripts/session.sh bench-ab r06_s2 "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_WIDE_EDGES=3" "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=1" "GCAST_WIDE_EDGES=3"
     ;;
+  s3)
+    # Round-6 session 3: gc_tuning.wide_edges = 3 as the shipped default (every edge update of >= 4096 tiles in the wide
+    # form) -- the default against its parts and against the other switches that could interact with an all-wide step;
+    # then the sizes the headline does not show: the 1 deg step, an 8-way rank (emulated), the bf16 tier.
+    bash scripts/session.sh bench-ab r06_s3 "GCAST_WIDE_EDGES=3" "GCAST_WIDE_EDGES=0" "GCAST_WIDE_EDGES=2" "GCAST_WIDE_EDGES=3 GCAST_PRIO=0,0,0" \
+        "GCAST_WIDE_EDGES=3 GCAST_TILE_QUEUE=0" "GCAST_WIDE_EDGES=3" "GCAST_WIDE_EDGES=0"
+    timeout 600 python bench.py --config 1deg_13L_M5 --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_1deg.json" 2> "$OUT/bench_1deg.err"; echo "1deg rc=$?"; show "$OUT/bench_1deg.json"
+    timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8.json" 2>&1 | tail -2 | cut -c1-700
+    timeout 600 python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; echo "bf16 rc=$?"; show "$OUT/bench_bf16.json"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

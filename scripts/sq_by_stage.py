@@ -32,13 +32,15 @@ STAGES = (["enc_embed_grid", "enc_edge", "enc_node_mesh", "enc_node_grid"]
 
 def main():
   per = defaultdict(dict)           # counter -> {dispatch id: value}
+  # (--bf16: the GC_PREC_BF16 tier's kernel instead of the f16x3 forms)
+  kernels = ("rowmlpbf_kernel",) if "--bf16" in sys.argv else ("rowmlp16h_kernel", "rowmlp16d_kernel", "rowmlp16w_kernel")
   for root in [a for a in sys.argv[1:] if not a.startswith("--")]:
     files = [root] if os.path.isfile(root) else glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)
     for f in files:
       with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
           k = r["Kernel_Name"]
-          if ("rowmlp16h_kernel" in k or "rowmlp16d_kernel" in k or "rowmlp16w_kernel" in k) and "<0" not in k:
+          if any(name in k for name in kernels) and "<0" not in k:
             d = per[r["Counter_Name"]]
             d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
   out = {}
