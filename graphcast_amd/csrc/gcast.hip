@@ -780,6 +780,7 @@ gc_tuning tuning_from_env() {
   t.tile_queue = env_int("GCAST_TILE_QUEUE", 1) != 0;
   { const char* e = std::getenv("GCAST_FUSE"); t.fuse = !(e && std::strcmp(e, "0") == 0); }
   { const char* e = std::getenv("GCAST_ONEPASS"); t.onepass = !(e && std::strcmp(e, "0") == 0); }
+  t.split_tail = env_int("GCAST_SPLIT_TAIL", GC_SPLIT_TAIL_DEFAULT) != 0;
   return t;
 }
 gc_tuning& tuning_mut() {
@@ -793,7 +794,7 @@ bool tuning_valid(const gc_tuning& t) {
          !(t.prio_other & ~3) && !(t.prio_stage & ~3) && t.helpers >= -1 && t.helpers <= 1 && b(t.helpers_small) &&
          t.helpers_edge >= 0 && t.helpers_edge <= 2 && t.helper_store >= 0 && t.helper_store <= 2 && t.helpers_min_rows >= 0 &&
          b(t.wide) && !(t.wide_edges & ~3) && (t.bf16_rows == 0 || t.bf16_rows == 64 || t.bf16_rows == 128) && b(t.tile_queue) &&
-         b(t.fuse) && b(t.onepass);
+         b(t.fuse) && b(t.onepass) && b(t.split_tail);
 }
 int half_grid_cap() { return tuning().grid_cap; }
 bool half_tile_xcd() { return tuning().tile_map_xcd != 0; }
@@ -841,6 +842,30 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
                            (tuning().wide_edges & (ONEPASS != 0 ? 1 : 2)) && tuning().helpers != 1 &&
                            (d.n_rows + kHRows - 1) / kHRows >= GC_WIDE_EDGE_MIN_TILES;
     if ((d.flags & GC_WG_WIDE) || wide_edge) return launch_rowmlp_half_w<MODE, ONEPASS>(d, s);
+  }
+  // Round 6: a node-side launch of 513 .. 768 tiles (the 0.25 deg processor's node updates: 641) is 1.6 rounds of
+  // four-wave pairs -- a full round, then 129 lone workgroups on 129 CUs while the other 127 idle, each lone tile at
+  // 0.6 of the pair's time.  Split in two launches: the first 512 tiles as ONE full round of 256 wide tiles (the wide
+  // form's rate: ~7 % faster per row), the remaining <= 256 tiles in the helper form (the faster form of a LONE tile:
+  // 142 k against 153 k cycles).  Rows are independent and every form gives the same bits.
+  if constexpr (MODE == GC_MODE_MLP_LN && ONEPASS == 0) {
+    const int t64 = (d.n_rows + kHRows - 1) / kHRows;
+    if (tuning().split_tail && tuning().helpers == -1 && !d.seg && !d.g0 && !d.g1 && d.k0 + d.k1 > 0 &&
+        !(d.flags & (GC_WG_WIDE | GC_WG_HELPERS | GC_WG_NO_HELPERS)) && t64 > GC_SCRATCH_SLOTS && t64 <= GC_SCRATCH_SLOTS * 3 / 2) {
+      const int head_rows = GC_SCRATCH_SLOTS * kHRows;
+      gc_rowmlp_desc head = d, tail = d;
+      head.n_rows = head_rows;
+      head.flags |= GC_WG_WIDE;
+      tail.n_rows = d.n_rows - head_rows;
+      tail.flags |= GC_WG_HELPERS;
+      auto rows = [&](const float* p, int ld) { return p ? p + (size_t)head_rows * ld : p; };
+      tail.a0 = rows(d.a0, d.lda0); tail.a1 = rows(d.a1, d.lda1); tail.d = rows(d.d, d.ldd);
+      tail.res = rows(d.res, d.ldres); tail.out = const_cast<float*>(rows(d.out, d.ldo));
+      for (int k = 0; k < d.n_chain; ++k)
+        if (d.chain[k].out) tail.chain[k].out = d.chain[k].out + (size_t)head_rows * d.chain[k].ldo;
+      if (const int rc = launch_rowmlp_half_w<MODE, ONEPASS>(head, s)) return rc;
+      return launch_rowmlp_half_d<MODE, ONEPASS>(tail, s);
+    }
   }
   // Which form.  Asked for per launch (GC_WG_HELPERS / GC_WG_NO_HELPERS), or per process (GCAST_HELPERS); otherwise:
   // a launch of at most one tile per CU runs one four-wave workgroup per CU anyway -- for the node-side launches (no
@@ -1347,10 +1372,10 @@ const char* gc_tuning_string(const gc_tuning* tp) {
   const gc_tuning& t = tp ? *tp : tuning();
   std::snprintf(buf, sizeof(buf),
                 "grid_cap=%d;tile_map=%s;prio=%d,%d,%d%s;helpers=%d;helpers_small=%d;helpers_edge=%d;helper_store=%d;"
-                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d",
+                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d;split_tail=%d",
                 t.grid_cap, t.tile_map_xcd ? "xcd" : "rr", t.prio_gemm, t.prio_other, t.prio_stage, t.prio_set ? "(set)" : "",
                 t.helpers, t.helpers_small, t.helpers_edge, t.helper_store, t.helpers_min_rows, t.wide, t.wide_edges, t.bf16_rows,
-                t.tile_queue, t.fuse, t.onepass);
+                t.tile_queue, t.fuse, t.onepass, t.split_tail);
   return buf;
 }
 

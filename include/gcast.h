@@ -504,13 +504,20 @@ typedef struct gc_tuning {
   int tile_queue;        /* GCAST_TILE_QUEUE: 0 = static tile walk whatever the descriptor says; default 1 */
   int fuse;              /* GCAST_FUSE: plan: the chained launch program (default 1); 0 = one launch per reference layer group */
   int onepass;           /* GCAST_ONEPASS: plan: one-pass edge updates where the first layer is all addends (default 1) */
-  int reserved[8];
+  int split_tail;        /* GCAST_SPLIT_TAIL (round 6): a two-pass launch without gather / segment-sum of 513 .. 768 tiles (the
+                            processor's node updates at 0.25 deg: 641) runs as TWO launches -- its first 512 tiles in the wide
+                            form (one full round of 256 wide tiles), the rest in the helper form -- instead of 1.6 rounds of
+                            four-wave pairs whose second round leaves half the chip idle; default 1 */
+  int reserved[7];
 } gc_tuning;
 int gc_get_tuning(gc_tuning* out);
 int gc_set_tuning(const gc_tuning* t);          /* GC_EINVAL (and no change) for a value outside its range */
 int gc_plan_get_tuning(const gc_plan* plan, gc_tuning* out);
 const char* gc_tuning_string(const gc_tuning* t);
 #define GC_WIDE_EDGE_MIN_TILES 4096   /* 64-row tiles: >= 8 rounds of 256 wide tiles */
+#ifndef GC_SPLIT_TAIL_DEFAULT
+#define GC_SPLIT_TAIL_DEFAULT 1       /* gc_tuning.split_tail of a process that does not set GCAST_SPLIT_TAIL */
+#endif
 #ifndef GC_WIDE_EDGES_DEFAULT
 #define GC_WIDE_EDGES_DEFAULT 3       /* gc_tuning.wide_edges of a process that does not set GCAST_WIDE_EDGES */
 #endif

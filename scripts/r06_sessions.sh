@@ -50,5 +50,13 @@ case "$NAME" in
     timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8.json" 2>&1 | tail -2 | cut -c1-700
     timeout 600 python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; echo "bf16 rc=$?"; show "$OUT/bench_bf16.json"
     ;;
+  s4)
+    # Round-6 session 4: gc_tuning.split_tail -- the processor's node updates (641 tiles = 1.6 rounds of four-wave pairs) as
+    # one full round of wide tiles + a helper-form tail: bit-identity (per launch, and the full-size step's properties),
+    # then same-session A/B.
+    timeout 1500 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "split tail"
+    bash scripts/session.sh bench-ab r06_s4 "GCAST_SPLIT_TAIL=1" "GCAST_SPLIT_TAIL=0" "GCAST_SPLIT_TAIL=1" "GCAST_SPLIT_TAIL=0" "GCAST_SPLIT_TAIL=1 GCAST_PRIO=0,0,0"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

@@ -501,6 +501,55 @@ def test_half_chain_two_row_stages(dev, n_rows):
   assert_close(o_r.cpu().numpy(), h32 @ wr.astype(np.float64) + br, "chain stage 1 (rows . W_r + b)")
 
 
+def test_node_update_of_one_and_a_half_rounds_is_split_into_a_wide_round_and_a_helper_tail(dev):
+  """Round 6 (gc_tuning.split_tail): the 0.25 deg processor's node update -- 40,962 rows = 641 tiles, K = 512 + 512,
+  residual, the next edge update's two products chained on -- is 1.6 rounds of four-wave pairs.  The launcher runs it
+  as TWO launches: rows 0 .. 32,767 as one full round of 256 wide tiles, the last 129 tiles (the final one partial) in
+  the helper form.  Same bits as the pinned four-wave form, in every output -- stored rows and both chained products --
+  and against the float64 oracle on a row sample."""
+  _half_only()
+  n_rows = 40962
+  rng = np.random.default_rng(7)
+  p = _mlp_ln_case(rng, n_rows, D, D)
+  res = rng.standard_normal((n_rows, D)).astype(np.float32)
+  ws, wr = asymmetric_weight(rng, D, D), asymmetric_weight(rng, D, D)
+  t = {k: up(v, dev) for k, v in dict(a0=p["a0"], a1=p["a1"], b1=p["b1"], b2=p["b2"], scale=p["scale"],
+                                       offset=p["offset"], res=res).items()}
+  tw1, tw2, tws, twr = up(pw1(p["w1"]), dev), up(pw2(p["w2"]), dev), up(pw2(ws), dev), up(pw2(wr), dev)
+
+  def launch(flags):
+    out = torch.full((n_rows, D), float("nan"), device=dev)
+    o_s = torch.full((n_rows, D + 32), float("nan"), device=dev)
+    o_r = torch.full((n_rows, D), float("nan"), device=dev)
+    d = new_desc(nat.MODE_MLP_LN, n_rows)
+    d.a0, d.lda0, d.k0, d.a1, d.lda1, d.k1 = t["a0"].data_ptr(), D, D, t["a1"].data_ptr(), D, D
+    d.w1p, d.b1, d.w2p, d.b2, d.n2 = tw1.data_ptr(), t["b1"].data_ptr(), tw2.data_ptr(), t["b2"].data_ptr(), D
+    d.ln_scale, d.ln_offset = t["scale"].data_ptr(), t["offset"].data_ptr()
+    d.res, d.ldres, d.out, d.ldo = t["res"].data_ptr(), D, out.data_ptr(), D
+    d.n_chain, d.flags = 2, flags
+    _chain_stage(d, 0, tws, nat.CHAIN_ROWS, out=o_s, ldo=D + 32)
+    _chain_stage(d, 1, twr, nat.CHAIN_ROWS, out=o_r, ldo=D)
+    run(d)
+    return out, o_s, o_r
+
+  assert nat.get_tuning().split_tail == 1 and nat.get_tuning().helpers == -1
+  want = launch(nat.WG_NO_HELPERS)
+  got = launch(0)                                      # no form pinned: the split rule applies
+  for a, b in zip(got, want):
+    assert torch.equal(a[:, :D], b[:, :D])             # (NaN padding of the wider stride excluded)
+    assert torch.isfinite(a[:, :D]).all()
+  prev = nat.set_tuning(split_tail=0)
+  try:
+    off = launch(0)
+  finally:
+    nat.set_tuning(prev)
+  for a, b in zip(off, want):
+    assert torch.equal(a[:, :D], b[:, :D])
+  pick = np.r_[0:3, 32766:32770, n_rows - 3:n_rows]    # the seam between the two launches and both ends
+  sub = {k: (v[pick] if k in ("a0", "a1") else v) for k, v in p.items()}
+  assert_close(got[0].cpu().numpy()[pick], _mlp_ln_want(sub) + res[pick], "split node update: stored rows")
+
+
 @pytest.mark.parametrize("n_rows,n_out", [(64, 227), (333, 83), (500, 240)])
 def test_half_chain_output_mlp(dev, n_rows, n_out):
   """Decoder node update with the output MLP chained on (engine: dec_node -> swish(h.W1 + b1).W2 + b2,
