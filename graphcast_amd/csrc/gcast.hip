@@ -781,6 +781,7 @@ gc_tuning tuning_from_env() {
   { const char* e = std::getenv("GCAST_FUSE"); t.fuse = !(e && std::strcmp(e, "0") == 0); }
   { const char* e = std::getenv("GCAST_ONEPASS"); t.onepass = !(e && std::strcmp(e, "0") == 0); }
   t.split_tail = env_int("GCAST_SPLIT_TAIL", GC_SPLIT_TAIL_DEFAULT) != 0;
+  t.bf16_stream = env_int("GCAST_BF16_STREAM", GC_BF16_STREAM_DEFAULT) != 0;
   return t;
 }
 gc_tuning& tuning_mut() {
@@ -794,7 +795,7 @@ bool tuning_valid(const gc_tuning& t) {
          !(t.prio_other & ~3) && !(t.prio_stage & ~3) && t.helpers >= -1 && t.helpers <= 1 && b(t.helpers_small) &&
          t.helpers_edge >= 0 && t.helpers_edge <= 2 && t.helper_store >= 0 && t.helper_store <= 2 && t.helpers_min_rows >= 0 &&
          b(t.wide) && !(t.wide_edges & ~3) && (t.bf16_rows == 0 || t.bf16_rows == 64 || t.bf16_rows == 128) && b(t.tile_queue) &&
-         b(t.fuse) && b(t.onepass) && b(t.split_tail);
+         b(t.fuse) && b(t.onepass) && b(t.split_tail) && b(t.bf16_stream);
 }
 int half_grid_cap() { return tuning().grid_cap; }
 bool half_tile_xcd() { return tuning().tile_map_xcd != 0; }
@@ -985,8 +986,6 @@ int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
   return launch_rowmlp_half_d2<MODE, ONEPASS, 0>(d, s);
 }
 
-bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};
-
 // Rows per workgroup of a GC_PREC_BF16 launch: 64 (two workgroups per CU), or 128 (eight waves sharing
 // one weight stream, one workgroup per CU) for the big node-side launches -- no gather, no segment-sum,
 // at least kBfWideMinRows rows: measured 6-7 % faster there, 1-7 % slower on the edge updates
@@ -995,12 +994,12 @@ bool g_bf_attr_set[2][2] = {{false, false}, {false, false}};
 constexpr int kBfWideMinRows = 128 * 256 * 2;
 int bf16_rows_override() { return tuning().bf16_rows; }
 
-template <bool F32ROWS, int NW>
+template <bool F32ROWS, int NW, bool STREAM>
 int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = BfLds<NW>::kFloats * sizeof(float);
-  bool& attr_set = g_bf_attr_set[F32ROWS][NW / 8];
+  static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpbf_kernel<F32ROWS, NW>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpbf_kernel<F32ROWS, NW, STREAM>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
@@ -1013,7 +1012,7 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   gc_rowmlp_desc dd = d;
   if (!tile_queue_pays(dd, tiles, tiles < slots ? tiles : slots)) dd.tile_queue = nullptr;
   apply_prio(dd, true);
-  hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, dd);
+  hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW, STREAM>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, dd);
   return check_launch("rowmlpbf_kernel");
 }
 
@@ -1021,7 +1020,13 @@ template <bool F32ROWS>
 int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   const int pin = (d.flags & GC_WG_ROWS_128) ? 128 : (d.flags & GC_WG_ROWS_64) ? 64 : bf16_rows_override();
   const bool wide = pin == 128 || (pin != 64 && d.n_rows >= kBfWideMinRows && !d.seg && !d.g0 && !d.g1);
-  return wide ? launch_rowmlp_bf16<F32ROWS, 8>(d, s) : launch_rowmlp_bf16<F32ROWS, 4>(d, s);
+  // Round 6 (gc_tuning.bf16_stream): an edge update without a layer-1 GEMM -- the whole first layer folded into addend
+  // rows -- forms every K step's hidden pair on the fly instead of gathering up front (rowmlp_bf16.inc: STREAM).
+  if constexpr (!F32ROWS) {
+    if (tuning().bf16_stream && d.k0 + d.k1 == 0 && d.g0 && d.n_chain == 0)
+      return wide ? launch_rowmlp_bf16<F32ROWS, 8, true>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, true>(d, s);
+  }
+  return wide ? launch_rowmlp_bf16<F32ROWS, 8, false>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, false>(d, s);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
@@ -1372,10 +1377,10 @@ const char* gc_tuning_string(const gc_tuning* tp) {
   const gc_tuning& t = tp ? *tp : tuning();
   std::snprintf(buf, sizeof(buf),
                 "grid_cap=%d;tile_map=%s;prio=%d,%d,%d%s;helpers=%d;helpers_small=%d;helpers_edge=%d;helper_store=%d;"
-                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d;split_tail=%d",
+                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d;split_tail=%d;bf16_stream=%d",
                 t.grid_cap, t.tile_map_xcd ? "xcd" : "rr", t.prio_gemm, t.prio_other, t.prio_stage, t.prio_set ? "(set)" : "",
                 t.helpers, t.helpers_small, t.helpers_edge, t.helper_store, t.helpers_min_rows, t.wide, t.wide_edges, t.bf16_rows,
-                t.tile_queue, t.fuse, t.onepass, t.split_tail);
+                t.tile_queue, t.fuse, t.onepass, t.split_tail, t.bf16_stream);
   return buf;
 }
 

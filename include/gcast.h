@@ -507,16 +507,22 @@ typedef struct gc_tuning {
   int split_tail;        /* GCAST_SPLIT_TAIL (round 6): a two-pass launch without gather / segment-sum of 513 .. 768 tiles (the
                             processor's node updates at 0.25 deg: 641) runs as TWO launches -- its first 512 tiles in the wide
                             form (one full round of 256 wide tiles), the rest in the helper form -- instead of 1.6 rounds of
-                            four-wave pairs whose second round leaves half the chip idle; default 1 */
-  int reserved[7];
+                            four-wave pairs whose second round leaves half the chip idle.  Measured (profiles/r06_s4_*): that
+                            stage 2 % faster, the power-limited step unchanged -- default 0 */
+  int bf16_stream;       /* GCAST_BF16_STREAM (round 6): GC_PREC_BF16 edge updates without a layer-1 GEMM form every K step's hidden
+                            pair on the fly from addend loads four K steps ahead instead of gathering up front; default 1 */
+  int reserved[6];
 } gc_tuning;
 int gc_get_tuning(gc_tuning* out);
 int gc_set_tuning(const gc_tuning* t);          /* GC_EINVAL (and no change) for a value outside its range */
 int gc_plan_get_tuning(const gc_plan* plan, gc_tuning* out);
 const char* gc_tuning_string(const gc_tuning* t);
 #define GC_WIDE_EDGE_MIN_TILES 4096   /* 64-row tiles: >= 8 rounds of 256 wide tiles */
+#ifndef GC_BF16_STREAM_DEFAULT
+#define GC_BF16_STREAM_DEFAULT 1      /* gc_tuning.bf16_stream of a process that does not set GCAST_BF16_STREAM */
+#endif
 #ifndef GC_SPLIT_TAIL_DEFAULT
-#define GC_SPLIT_TAIL_DEFAULT 1       /* gc_tuning.split_tail of a process that does not set GCAST_SPLIT_TAIL */
+#define GC_SPLIT_TAIL_DEFAULT 0       /* gc_tuning.split_tail of a process that does not set GCAST_SPLIT_TAIL */
 #endif
 #ifndef GC_WIDE_EDGES_DEFAULT
 #define GC_WIDE_EDGES_DEFAULT 3       /* gc_tuning.wide_edges of a process that does not set GCAST_WIDE_EDGES */

@@ -58,5 +58,16 @@ case "$NAME" in
     gate "$OUT/pytest.log" "split tail"
     bash scripts/session.sh bench-ab r06_s4 "GCAST_SPLIT_TAIL=1" "GCAST_SPLIT_TAIL=0" "GCAST_SPLIT_TAIL=1" "GCAST_SPLIT_TAIL=0" "GCAST_SPLIT_TAIL=1 GCAST_PRIO=0,0,0"
     ;;
+  s5)
+    # Round-6 session 5: the Bfloat16Cast tier's streamed edge updates (gc_tuning.bf16_stream: launches without a layer-1
+    # GEMM form every K step's hidden pair on the fly) -- bit-identity with the unstreamed launch and the tier's oracle
+    # tests first (run under a timeout of their own: new counted waits), then same-session A/B of the tier's step, plus
+    # the 128-row workgroups on every launch as a reference point.
+    timeout 900 python -m pytest tests/test_bf16_tier_gpu.py tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=300 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "bf16 stream"
+    bash scripts/session.sh bench-ab r06_s5 --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 --precision bf16 -- \
+        "GCAST_BF16_STREAM=1" "GCAST_BF16_STREAM=0" "GCAST_BF16_STREAM=1" "GCAST_BF16_STREAM=0" "GCAST_BF16_STREAM=1 GCAST_BF16_ROWS=128"
+    timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

@@ -155,7 +155,7 @@ def test_node_like_launch_with_residual(dev, n_rows, k0, k1):
   assert ulps <= 1.0 and err <= 2 * ULP
 
 
-@pytest.mark.parametrize("kind", ["mesh_like", "uniform3", "with_empty_and_skew", "many_tiles"])
+@pytest.mark.parametrize("kind", ["mesh_like", "uniform3", "with_empty_and_skew", "many_tiles", "many_tiles_no_rows"])
 def test_edge_launch_with_gathers_and_segment_sum(dev, kind):
   """d + g0[snd] + g1[rcv] (+ rows . W1) -> MLP -> LN -> residual / rows out + receiver segment-sum
   (fp32 run sums, bfloat16 aggregate rows; straddling runs through fp32 partials + gc_seg_fixup_bf16)."""
@@ -164,7 +164,7 @@ def test_edge_launch_with_gathers_and_segment_sum(dev, kind):
     n_recv, deg = 400, rng.integers(5, 37, 400)
   elif kind == "uniform3":
     n_recv, deg = 500, np.full(500, 3)
-  elif kind == "many_tiles":
+  elif kind in ("many_tiles", "many_tiles_no_rows"):
     n_recv, deg = 9000, rng.integers(2, 9, 9000)
   else:
     n_recv, deg = 60, rng.integers(0, 12, 60)
@@ -174,7 +174,7 @@ def test_edge_launch_with_gathers_and_segment_sum(dev, kind):
   n_send = 90
   senders = rng.integers(0, n_send, len(receivers))
   pk = packing.pack_edges(senders, receivers, n_recv)
-  use_rows = kind != "uniform3"                                   # the decoder edge update has no GEMM-1 rows
+  use_rows = kind not in ("uniform3", "many_tiles_no_rows")       # the encoder / decoder edge updates have no GEMM-1 rows
   p = case(rng, pk.n_rows, D if use_rows else 0)
   dd = rng.standard_normal((pk.n_rows, D)).astype(np.float32)
   gs = rng.standard_normal((n_send, D)).astype(np.float32)
@@ -217,6 +217,27 @@ def test_edge_launch_with_gathers_and_segment_sum(dev, kind):
   assert torch.equal(wide[0], narrow[0]) and torch.equal(wide[1].view(torch.int16), narrow[1].view(torch.int16))
   launch(0)
   assert torch.equal(out, narrow[0]) and torch.equal(agg.view(torch.int16), narrow[1].view(torch.int16))
+  if not use_rows:
+    # round 6 (gc_tuning.bf16_stream, the default): a launch without GEMM-1 rows forms every K step's hidden pair on the
+    # fly from addend loads four K steps ahead instead of gathering up front -- the same sums in the same order: the same
+    # bits as the unstreamed launch, in both workgroup sizes, with three addend sources and with two (the encoder's edge
+    # update has no receiver term: the absent source reads the zero row)
+    assert nat.get_tuning().bf16_stream == 1
+    prev = nat.set_tuning(bf16_stream=0)
+    try:
+      for pin in (nat.WG_ROWS_64, nat.WG_ROWS_128):
+        unstreamed = launch(pin)
+        assert torch.equal(unstreamed[0], narrow[0]) and torch.equal(unstreamed[1].view(torch.int16), narrow[1].view(torch.int16))
+      d.g1, d.idx1 = None, None
+      two_unstreamed = launch(nat.WG_ROWS_64)
+    finally:
+      nat.set_tuning(prev)
+    for pin in (nat.WG_ROWS_64, nat.WG_ROWS_128):
+      two = launch(pin)
+      assert torch.equal(two[0], two_unstreamed[0]) and torch.equal(two[1].view(torch.int16), two_unstreamed[1].view(torch.int16))
+    assert not torch.equal(two_unstreamed[0], narrow[0])          # (the receiver term does matter)
+    d.g1, d.idx1 = t["gr"].data_ptr(), t["rcv"].data_ptr()
+    launch(0)
   ok = pk.receivers >= 0
   z = rb(dd) + rb(gs)[np.maximum(pk.senders, 0)] + rb(gr)[np.maximum(pk.receivers, 0)] + rb(p["b1"])
   if use_rows:

@@ -503,8 +503,8 @@ def test_half_chain_two_row_stages(dev, n_rows):
 
 def test_node_update_of_one_and_a_half_rounds_is_split_into_a_wide_round_and_a_helper_tail(dev):
   """Round 6 (gc_tuning.split_tail): the 0.25 deg processor's node update -- 40,962 rows = 641 tiles, K = 512 + 512,
-  residual, the next edge update's two products chained on -- is 1.6 rounds of four-wave pairs.  The launcher runs it
-  as TWO launches: rows 0 .. 32,767 as one full round of 256 wide tiles, the last 129 tiles (the final one partial) in
+  residual, the next edge update's two products chained on -- is 1.6 rounds of four-wave pairs.  With split_tail set the
+  launcher runs it as TWO launches: rows 0 .. 32,767 as one full round of 256 wide tiles, the last 129 tiles (the final one partial) in
   the helper form.  Same bits as the pinned four-wave form, in every output -- stored rows and both chained products --
   and against the float64 oracle on a row sample."""
   _half_only()
@@ -532,17 +532,17 @@ def test_node_update_of_one_and_a_half_rounds_is_split_into_a_wide_round_and_a_h
     run(d)
     return out, o_s, o_r
 
-  assert nat.get_tuning().split_tail == 1 and nat.get_tuning().helpers == -1
+  assert nat.get_tuning().helpers == -1
   want = launch(nat.WG_NO_HELPERS)
-  got = launch(0)                                      # no form pinned: the split rule applies
+  prev = nat.set_tuning(split_tail=1)                  # (off by default: that stage 2 % faster, the power-limited step not)
+  try:
+    got = launch(0)                                    # no form pinned: the split rule applies
+  finally:
+    nat.set_tuning(prev)
   for a, b in zip(got, want):
     assert torch.equal(a[:, :D], b[:, :D])             # (NaN padding of the wider stride excluded)
     assert torch.isfinite(a[:, :D]).all()
-  prev = nat.set_tuning(split_tail=0)
-  try:
-    off = launch(0)
-  finally:
-    nat.set_tuning(prev)
+  off = launch(0)
   for a, b in zip(off, want):
     assert torch.equal(a[:, :D], b[:, :D])
   pick = np.r_[0:3, 32766:32770, n_rows - 3:n_rows]    # the seam between the two launches and both ends
