@@ -781,7 +781,7 @@ gc_tuning tuning_from_env() {
   { const char* e = std::getenv("GCAST_FUSE"); t.fuse = !(e && std::strcmp(e, "0") == 0); }
   { const char* e = std::getenv("GCAST_ONEPASS"); t.onepass = !(e && std::strcmp(e, "0") == 0); }
   t.split_tail = env_int("GCAST_SPLIT_TAIL", GC_SPLIT_TAIL_DEFAULT) != 0;
-  t.bf16_stream = env_int("GCAST_BF16_STREAM", GC_BF16_STREAM_DEFAULT) != 0;
+  t.bf16_stream = env_int("GCAST_BF16_STREAM", GC_BF16_STREAM_DEFAULT) & 3;
   return t;
 }
 gc_tuning& tuning_mut() {
@@ -795,7 +795,7 @@ bool tuning_valid(const gc_tuning& t) {
          !(t.prio_other & ~3) && !(t.prio_stage & ~3) && t.helpers >= -1 && t.helpers <= 1 && b(t.helpers_small) &&
          t.helpers_edge >= 0 && t.helpers_edge <= 2 && t.helper_store >= 0 && t.helper_store <= 2 && t.helpers_min_rows >= 0 &&
          b(t.wide) && !(t.wide_edges & ~3) && (t.bf16_rows == 0 || t.bf16_rows == 64 || t.bf16_rows == 128) && b(t.tile_queue) &&
-         b(t.fuse) && b(t.onepass) && b(t.split_tail) && b(t.bf16_stream);
+         b(t.fuse) && b(t.onepass) && b(t.split_tail) && !(t.bf16_stream & ~3);
 }
 int half_grid_cap() { return tuning().grid_cap; }
 bool half_tile_xcd() { return tuning().tile_map_xcd != 0; }
@@ -1023,8 +1023,14 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   // Round 6 (gc_tuning.bf16_stream): an edge update without a layer-1 GEMM -- the whole first layer folded into addend
   // rows -- forms every K step's hidden pair on the fly instead of gathering up front (rowmlp_bf16.inc: STREAM).
   if constexpr (!F32ROWS) {
-    if (tuning().bf16_stream && d.k0 + d.k1 == 0 && d.g0 && d.n_chain == 0)
+    if ((tuning().bf16_stream & 1) && d.k0 + d.k1 == 0 && d.g0 && d.n_chain == 0)
       return wide ? launch_rowmlp_bf16<F32ROWS, 8, true>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, true>(d, s);
+    // ... and one WITH a layer-1 GEMM adds its gathered rows when the hidden layer is formed (GC_LATE_ADDENDS)
+    if ((tuning().bf16_stream & 2) && d.k0 + d.k1 > 0 && d.g0 && !d.d) {
+      gc_rowmlp_desc dd = d;
+      dd.flags |= GC_LATE_ADDENDS;
+      return wide ? launch_rowmlp_bf16<F32ROWS, 8, false>(dd, s) : launch_rowmlp_bf16<F32ROWS, 4, false>(dd, s);
+    }
   }
   return wide ? launch_rowmlp_bf16<F32ROWS, 8, false>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, false>(d, s);
 }

@@ -114,6 +114,12 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /
                                   * CU -- 128 rows against one weight ring, half the L2 -> LDS stream per row
                                   * (csrc/rowmlp_half.inc: rowmlp16w_kernel).  Same bits.  Round 6: also launches with a
                                   * segment-sum and the one-pass (GC_W2_NATURAL) ones.  Ignored in other modes. */
+#define GC_LATE_ADDENDS 512      /* GC_PREC_BF16 launches WITH a layer-1 GEMM whose addends are gathered rows (the processor's edge
+                                  * update): the gathered rows are added when the hidden layer is formed -- loads pipelined
+                                  * four pairs ahead under the swish bursts -- instead of in a burst in front of layer 1.
+                                  * (b1 + products) + g0 + g1 instead of (b1 + g0 + g1) + products: another fp32
+                                  * association in front of the SAME bfloat16 rounding, not the same bits.  Set by the
+                                  * launcher when gc_tuning.bf16_stream is on; ignored elsewhere. */
 #define GC_WIDE_MIN_ROWS 262144   /* the plan asks for GC_WG_WIDE from this many rows on (>= 8 rounds of 256 128-row tiles:
                                   * below, the doubled tail costs more than the shared ring saves) */
 #define GC_TILE_QUEUE_ANY 128    /* gc_rowmlp_desc.tile_queue: hand the tiles out dynamically whenever the launch has more
@@ -510,7 +516,9 @@ typedef struct gc_tuning {
                             four-wave pairs whose second round leaves half the chip idle.  Measured (profiles/r06_s4_*): that
                             stage 2 % faster, the power-limited step unchanged -- default 0 */
   int bf16_stream;       /* GCAST_BF16_STREAM (round 6): GC_PREC_BF16 edge updates without a layer-1 GEMM form every K step's hidden
-                            pair on the fly from addend loads four K steps ahead instead of gathering up front; default 1 */
+                            pair on the fly from addend loads four K steps ahead instead of gathering up front (same bits); bit 1:
+                            those WITH a layer-1 GEMM add their gathered rows when the hidden layer is formed (GC_LATE_ADDENDS);
+                            0 .. 3, default 3 */
   int reserved[6];
 } gc_tuning;
 int gc_get_tuning(gc_tuning* out);
@@ -519,7 +527,7 @@ int gc_plan_get_tuning(const gc_plan* plan, gc_tuning* out);
 const char* gc_tuning_string(const gc_tuning* t);
 #define GC_WIDE_EDGE_MIN_TILES 4096   /* 64-row tiles: >= 8 rounds of 256 wide tiles */
 #ifndef GC_BF16_STREAM_DEFAULT
-#define GC_BF16_STREAM_DEFAULT 1      /* gc_tuning.bf16_stream of a process that does not set GCAST_BF16_STREAM */
+#define GC_BF16_STREAM_DEFAULT 3      /* gc_tuning.bf16_stream of a process that does not set GCAST_BF16_STREAM */
 #endif
 #ifndef GC_SPLIT_TAIL_DEFAULT
 #define GC_SPLIT_TAIL_DEFAULT 0       /* gc_tuning.split_tail of a process that does not set GCAST_SPLIT_TAIL */

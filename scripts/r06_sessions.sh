@@ -69,5 +69,16 @@ case "$NAME" in
         "GCAST_BF16_STREAM=1" "GCAST_BF16_STREAM=0" "GCAST_BF16_STREAM=1" "GCAST_BF16_STREAM=0" "GCAST_BF16_STREAM=1 GCAST_BF16_ROWS=128"
     timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
     ;;
+  s6)
+    # Round-6 session 6: the bf16 tier's LATE addends (GC_LATE_ADDENDS: the processor edge update adds its gathered rows
+    # when the hidden layer is formed) -- the tier's oracle tests (per launch, whole step, rollout, partition), then
+    # same-session A/B of gc_tuning.bf16_stream = 0 | 1 | 3.
+    timeout 900 python -m pytest tests/test_bf16_tier_gpu.py -m gpu -q -x --timeout=300 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "bf16 late addends"
+    grep "late addends" "$OUT/pytest.log" | cut -c1-200
+    bash scripts/session.sh bench-ab r06_s6 --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 --precision bf16 -- \
+        "GCAST_BF16_STREAM=3" "GCAST_BF16_STREAM=1" "GCAST_BF16_STREAM=0" "GCAST_BF16_STREAM=3" "GCAST_BF16_STREAM=1"
+    timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
