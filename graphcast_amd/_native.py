@@ -26,6 +26,7 @@ TILE_MAP_XCD = 16                                 # GC_TILE_XCD
 TILE_QUEUE_ANY = 128                              # GC_TILE_QUEUE_ANY: the dynamic tile queue whenever a launch has a second round
 WG_HELPERS, WG_NO_HELPERS = 32, 64                # GC_WG_HELPERS / GC_WG_NO_HELPERS (eight-wave form of a GC_LAYOUT_HALF launch)
 WG_WIDE = 256                                     # GC_WG_WIDE (eight MULTIPLYING waves per CU on one weight ring; round 6: segment-sum / one-pass launches too)
+LATE_ADDENDS = 512                                # GC_LATE_ADDENDS (bf16 tier / the f16x3 wide form: gathered rows added when the hidden layer is formed)
 WIDE_EDGES_DEFAULT = 3                            # GC_WIDE_EDGES_DEFAULT (gc_tuning.wide_edges of a process without GCAST_WIDE_EDGES)
 TILE_ROWS = 64
 K_CHUNK = 32
@@ -124,7 +125,7 @@ class Tuning(ctypes.Structure):
   _fields_ = [(name, ctypes.c_int) for name in (
       "grid_cap", "tile_map_xcd", "prio_set", "prio_gemm", "prio_other", "prio_stage", "helpers", "helpers_small",
       "helpers_edge", "helper_store", "helpers_min_rows", "wide", "wide_edges", "bf16_rows", "tile_queue", "fuse",
-      "onepass", "split_tail", "bf16_stream")] + [("reserved", ctypes.c_int * 6)]
+      "onepass", "split_tail", "bf16_stream", "wide_late")] + [("reserved", ctypes.c_int * 5)]
 
   def as_dict(self):
     return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
@@ -162,7 +163,8 @@ RESOURCE_LIMITS = {"rowmlp16h_kernel": dict(scratch=160, occupancy=2), "rowmlpbf
                    # the eight-wave helper form (one 512-thread workgroup per CU = two waves per SIMD: the same 256-register budget)
                    "rowmlp16d_kernel": dict(scratch=160, occupancy=2),
                    # the wide form (eight multiplying waves, one workgroup per CU): the same budget again
-                   "rowmlp16w_kernel": dict(scratch=160, occupancy=2)}
+                   # (round 6: + the late-addend instantiation of gc_tuning.wide_late)
+                   "rowmlp16w_kernel": dict(scratch=200, occupancy=2)}
 
 
 def check_resources(remarks, limits=None):

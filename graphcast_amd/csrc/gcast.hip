@@ -782,6 +782,7 @@ gc_tuning tuning_from_env() {
   { const char* e = std::getenv("GCAST_ONEPASS"); t.onepass = !(e && std::strcmp(e, "0") == 0); }
   t.split_tail = env_int("GCAST_SPLIT_TAIL", GC_SPLIT_TAIL_DEFAULT) != 0;
   t.bf16_stream = env_int("GCAST_BF16_STREAM", GC_BF16_STREAM_DEFAULT) & 3;
+  t.wide_late = env_int("GCAST_WIDE_LATE", GC_WIDE_LATE_DEFAULT) != 0;
   return t;
 }
 gc_tuning& tuning_mut() {
@@ -795,7 +796,7 @@ bool tuning_valid(const gc_tuning& t) {
          !(t.prio_other & ~3) && !(t.prio_stage & ~3) && t.helpers >= -1 && t.helpers <= 1 && b(t.helpers_small) &&
          t.helpers_edge >= 0 && t.helpers_edge <= 2 && t.helper_store >= 0 && t.helper_store <= 2 && t.helpers_min_rows >= 0 &&
          b(t.wide) && !(t.wide_edges & ~3) && (t.bf16_rows == 0 || t.bf16_rows == 64 || t.bf16_rows == 128) && b(t.tile_queue) &&
-         b(t.fuse) && b(t.onepass) && b(t.split_tail) && !(t.bf16_stream & ~3);
+         b(t.fuse) && b(t.onepass) && b(t.split_tail) && !(t.bf16_stream & ~3) && b(t.wide_late);
 }
 int half_grid_cap() { return tuning().grid_cap; }
 bool half_tile_xcd() { return tuning().tile_map_xcd != 0; }
@@ -827,7 +828,7 @@ inline bool tile_queue_pays(const gc_rowmlp_desc& d, int tiles, int grid) {
   return d.tile_queue && (tiles >= GC_TILE_QUEUE_MIN_ROUNDS * grid || ((d.flags & GC_TILE_QUEUE_ANY) && tiles > grid));
 }
 
-template <int MODE, int ONEPASS>
+template <int MODE, int ONEPASS, int LATE = 0>
 int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s);
 
 template <int MODE, int ONEPASS = 0>
@@ -842,7 +843,14 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
     const bool wide_edge = d.seg && !(d.flags & (GC_WG_HELPERS | GC_WG_NO_HELPERS)) &&
                            (tuning().wide_edges & (ONEPASS != 0 ? 1 : 2)) && tuning().helpers != 1 &&
                            (d.n_rows + kHRows - 1) / kHRows >= GC_WIDE_EDGE_MIN_TILES;
-    if ((d.flags & GC_WG_WIDE) || wide_edge) return launch_rowmlp_half_w<MODE, ONEPASS>(d, s);
+    if ((d.flags & GC_WG_WIDE) || wide_edge) {
+      // gc_tuning.wide_late (round 6): a wide two-pass edge update adds its gathered rows when the hidden layer is formed
+      if constexpr (ONEPASS == 0) {
+        if ((tuning().wide_late || (d.flags & GC_LATE_ADDENDS)) && d.seg && d.g0 && !d.d && d.k0 + d.k1 > 0)
+          return launch_rowmlp_half_w<MODE, ONEPASS, 1>(d, s);
+      }
+      return launch_rowmlp_half_w<MODE, ONEPASS>(d, s);
+    }
   }
   // Round 6: a node-side launch of 513 .. 768 tiles (the 0.25 deg processor's node updates: 641) is 1.6 rounds of
   // four-wave pairs -- a full round, then 129 lone workgroups on 129 CUs while the other 127 idle, each lone tile at
@@ -944,12 +952,12 @@ int launch_rowmlp_half_d2(const gc_rowmlp_desc& d, hipStream_t s) {
   return check_launch("rowmlp16d_kernel");
 }
 
-template <int MODE, int ONEPASS>
+template <int MODE, int ONEPASS, int LATE>
 int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = kWLdsFloats * sizeof(float);     // four-wave layout + the parking area (LDS share of the parked accumulators / second sub-tile)
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16w_kernel<MODE, ONEPASS>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16w_kernel<MODE, ONEPASS, LATE>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
@@ -964,7 +972,7 @@ int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s) {
   dd.flags &= ~GC_TILE_XCD;
   if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
   apply_prio(dd);
-  hipLaunchKernelGGL((rowmlp16w_kernel<MODE, ONEPASS>), dim3(grid), dim3(512), lds, s, dd);
+  hipLaunchKernelGGL((rowmlp16w_kernel<MODE, ONEPASS, LATE>), dim3(grid), dim3(512), lds, s, dd);
   return check_launch("rowmlp16w_kernel");
 }
 
@@ -994,12 +1002,12 @@ int launch_rowmlp_half_d(const gc_rowmlp_desc& d, hipStream_t s) {
 constexpr int kBfWideMinRows = 128 * 256 * 2;
 int bf16_rows_override() { return tuning().bf16_rows; }
 
-template <bool F32ROWS, int NW, bool STREAM>
+template <bool F32ROWS, int NW, int VAR>
 int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   const size_t lds = BfLds<NW>::kFloats * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpbf_kernel<F32ROWS, NW, STREAM>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlpbf_kernel<F32ROWS, NW, VAR>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
@@ -1012,7 +1020,7 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   gc_rowmlp_desc dd = d;
   if (!tile_queue_pays(dd, tiles, tiles < slots ? tiles : slots)) dd.tile_queue = nullptr;
   apply_prio(dd, true);
-  hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW, STREAM>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, dd);
+  hipLaunchKernelGGL((rowmlpbf_kernel<F32ROWS, NW, VAR>), dim3(tiles < slots ? tiles : slots), dim3(64 * NW), lds, s, dd);
   return check_launch("rowmlpbf_kernel");
 }
 
@@ -1024,15 +1032,13 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   // rows -- forms every K step's hidden pair on the fly instead of gathering up front (rowmlp_bf16.inc: STREAM).
   if constexpr (!F32ROWS) {
     if ((tuning().bf16_stream & 1) && d.k0 + d.k1 == 0 && d.g0 && d.n_chain == 0)
-      return wide ? launch_rowmlp_bf16<F32ROWS, 8, true>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, true>(d, s);
-    // ... and one WITH a layer-1 GEMM adds its gathered rows when the hidden layer is formed (GC_LATE_ADDENDS)
-    if ((tuning().bf16_stream & 2) && d.k0 + d.k1 > 0 && d.g0 && !d.d) {
-      gc_rowmlp_desc dd = d;
-      dd.flags |= GC_LATE_ADDENDS;
-      return wide ? launch_rowmlp_bf16<F32ROWS, 8, false>(dd, s) : launch_rowmlp_bf16<F32ROWS, 4, false>(dd, s);
-    }
+      return wide ? launch_rowmlp_bf16<F32ROWS, 8, 1>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, 1>(d, s);
+    // ... and one WITH a layer-1 GEMM adds its gathered rows when the hidden layer is formed (GC_LATE_ADDENDS: its own
+    // instantiation of the kernel)
+    if (((tuning().bf16_stream & 2) || (d.flags & GC_LATE_ADDENDS)) && d.k0 + d.k1 > 0 && d.g0 && !d.d)
+      return wide ? launch_rowmlp_bf16<F32ROWS, 8, 2>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, 2>(d, s);
   }
-  return wide ? launch_rowmlp_bf16<F32ROWS, 8, false>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, false>(d, s);
+  return wide ? launch_rowmlp_bf16<F32ROWS, 8, 0>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, 0>(d, s);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
@@ -1383,10 +1389,10 @@ const char* gc_tuning_string(const gc_tuning* tp) {
   const gc_tuning& t = tp ? *tp : tuning();
   std::snprintf(buf, sizeof(buf),
                 "grid_cap=%d;tile_map=%s;prio=%d,%d,%d%s;helpers=%d;helpers_small=%d;helpers_edge=%d;helper_store=%d;"
-                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d;split_tail=%d;bf16_stream=%d",
+                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d;split_tail=%d;bf16_stream=%d;wide_late=%d",
                 t.grid_cap, t.tile_map_xcd ? "xcd" : "rr", t.prio_gemm, t.prio_other, t.prio_stage, t.prio_set ? "(set)" : "",
                 t.helpers, t.helpers_small, t.helpers_edge, t.helper_store, t.helpers_min_rows, t.wide, t.wide_edges, t.bf16_rows,
-                t.tile_queue, t.fuse, t.onepass, t.split_tail, t.bf16_stream);
+                t.tile_queue, t.fuse, t.onepass, t.split_tail, t.bf16_stream, t.wide_late);
   return buf;
 }
 

@@ -114,7 +114,8 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /
                                   * CU -- 128 rows against one weight ring, half the L2 -> LDS stream per row
                                   * (csrc/rowmlp_half.inc: rowmlp16w_kernel).  Same bits.  Round 6: also launches with a
                                   * segment-sum and the one-pass (GC_W2_NATURAL) ones.  Ignored in other modes. */
-#define GC_LATE_ADDENDS 512      /* GC_PREC_BF16 launches WITH a layer-1 GEMM whose addends are gathered rows (the processor's edge
+#define GC_LATE_ADDENDS 512      /* (also honoured by the GC_PREC_F16X3 wide form: gc_tuning.wide_late)
+                                  * GC_PREC_BF16 launches WITH a layer-1 GEMM whose addends are gathered rows (the processor's edge
                                   * update): the gathered rows are added when the hidden layer is formed -- loads pipelined
                                   * four pairs ahead under the swish bursts -- instead of in a burst in front of layer 1.
                                   * (b1 + products) + g0 + g1 instead of (b1 + g0 + g1) + products: another fp32
@@ -519,13 +520,20 @@ typedef struct gc_tuning {
                             pair on the fly from addend loads four K steps ahead instead of gathering up front (same bits); bit 1:
                             those WITH a layer-1 GEMM add their gathered rows when the hidden layer is formed (GC_LATE_ADDENDS);
                             0 .. 3, default 3 */
-  int reserved[6];
+  int wide_late;         /* GCAST_WIDE_LATE (round 6): a two-pass edge update in the WIDE form adds its gathered rows when the hidden
+                            layer is formed (GC_LATE_ADDENDS) instead of in a burst in front of layer 1 that nothing multiplies
+                            under in that form.  Another fp32 association: that launch is then not bit-identical to the
+                            four-wave kernel (1e-7).  0 | 1 */
+  int reserved[5];
 } gc_tuning;
 int gc_get_tuning(gc_tuning* out);
 int gc_set_tuning(const gc_tuning* t);          /* GC_EINVAL (and no change) for a value outside its range */
 int gc_plan_get_tuning(const gc_plan* plan, gc_tuning* out);
 const char* gc_tuning_string(const gc_tuning* t);
 #define GC_WIDE_EDGE_MIN_TILES 4096   /* 64-row tiles: >= 8 rounds of 256 wide tiles */
+#ifndef GC_WIDE_LATE_DEFAULT
+#define GC_WIDE_LATE_DEFAULT 0        /* gc_tuning.wide_late of a process that does not set GCAST_WIDE_LATE */
+#endif
 #ifndef GC_BF16_STREAM_DEFAULT
 #define GC_BF16_STREAM_DEFAULT 3      /* gc_tuning.bf16_stream of a process that does not set GCAST_BF16_STREAM */
 #endif

@@ -80,5 +80,15 @@ case "$NAME" in
         "GCAST_BF16_STREAM=3" "GCAST_BF16_STREAM=1" "GCAST_BF16_STREAM=0" "GCAST_BF16_STREAM=3" "GCAST_BF16_STREAM=1"
     timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
     ;;
+  s7)
+    # Round-6 session 7: late addends -- the bf16 tier's processor edge update (its own kernel instantiation) and, as an
+    # experiment, the f16x3 wide form's (gc_tuning.wide_late; not bit-identical to the four-wave kernel): tests, then A/B.
+    timeout 900 python -m pytest tests/test_native_abi.py tests/test_bf16_tier_gpu.py tests/test_rowmlp_gpu.py -m gpu -q -x --timeout=300 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "late addends"
+    bash scripts/session.sh bench-ab r06_s7b --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 --precision bf16 -- \
+        "GCAST_BF16_STREAM=3" "GCAST_BF16_STREAM=1" "GCAST_BF16_STREAM=0" "GCAST_BF16_STREAM=3" "GCAST_BF16_STREAM=1"
+    bash scripts/session.sh bench-ab r06_s7 "GCAST_WIDE_LATE=0" "GCAST_WIDE_LATE=1" "GCAST_WIDE_LATE=0" "GCAST_WIDE_LATE=1"
+    timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

@@ -57,11 +57,11 @@ def test_tuning_is_one_struct_set_and_read_back(built):
   d = before.as_dict()
   assert set(d) == {"grid_cap", "tile_map_xcd", "prio_set", "prio_gemm", "prio_other", "prio_stage", "helpers",
                     "helpers_small", "helpers_edge", "helper_store", "helpers_min_rows", "wide", "wide_edges", "bf16_rows",
-                    "tile_queue", "fuse", "onepass", "split_tail", "bf16_stream"}
+                    "tile_queue", "fuse", "onepass", "split_tail", "bf16_stream", "wide_late"}
   if not any(k.startswith("GCAST_") for k in os.environ):      # the documented defaults of a process without overrides
     assert d == dict(grid_cap=512, tile_map_xcd=0, prio_set=0, prio_gemm=1, prio_other=0, prio_stage=0, helpers=-1,
                      helpers_small=1, helpers_edge=1, helper_store=2, helpers_min_rows=65536, wide=1,
-                     wide_edges=nat.WIDE_EDGES_DEFAULT, bf16_rows=0, tile_queue=1, fuse=1, onepass=1, split_tail=0, bf16_stream=3)
+                     wide_edges=nat.WIDE_EDGES_DEFAULT, bf16_rows=0, tile_queue=1, fuse=1, onepass=1, split_tail=0, bf16_stream=3, wide_late=0)
   try:
     prev = nat.set_tuning(grid_cap=256, helpers_edge=2, wide_edges=3, prio_gemm=2)
     assert bytes(prev) == bytes(before)
@@ -121,12 +121,13 @@ def test_python_constants_mirror_the_header():
                 GC_EINVAL=nat.EINVAL, GC_ELAUNCH=nat.ELAUNCH, GC_ERANGE=nat.ERANGE, GC_F16X3_MAX=nat.F16X3_MAX,
                 GC_ROWS_F32=nat.ROWS_F32, GC_W2_NATURAL=nat.W2_NATURAL, GC_WG_ROWS_64=nat.WG_ROWS_64,
                 GC_WG_ROWS_128=nat.WG_ROWS_128, GC_TILE_XCD=nat.TILE_MAP_XCD, GC_WG_HELPERS=nat.WG_HELPERS,
-                GC_WG_NO_HELPERS=nat.WG_NO_HELPERS, GC_TILE_QUEUE_ANY=nat.TILE_QUEUE_ANY, GC_MAX_CHAIN=nat.MAX_CHAIN)
+                GC_WG_NO_HELPERS=nat.WG_NO_HELPERS, GC_TILE_QUEUE_ANY=nat.TILE_QUEUE_ANY, GC_MAX_CHAIN=nat.MAX_CHAIN,
+                GC_WG_WIDE=nat.WG_WIDE, GC_LATE_ADDENDS=nat.LATE_ADDENDS)
   for name, value in mirror.items():
     assert name in defines, f"{name} not found in include/gcast.h"
     assert float(defines[name]) == float(value), (name, defines[name], value)
   flags = [mirror[k] for k in ("GC_ROWS_F32", "GC_W2_NATURAL", "GC_WG_ROWS_64", "GC_WG_ROWS_128", "GC_TILE_XCD",
-                               "GC_WG_HELPERS", "GC_WG_NO_HELPERS", "GC_TILE_QUEUE_ANY")]
+                               "GC_WG_HELPERS", "GC_WG_NO_HELPERS", "GC_TILE_QUEUE_ANY", "GC_WG_WIDE", "GC_LATE_ADDENDS")]
   assert sorted(flags) == [1 << i for i in range(len(flags))], "gc_rowmlp_desc.flags bits must be distinct"
 
 
