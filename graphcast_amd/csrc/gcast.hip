@@ -781,7 +781,7 @@ gc_tuning tuning_from_env() {
   { const char* e = std::getenv("GCAST_FUSE"); t.fuse = !(e && std::strcmp(e, "0") == 0); }
   { const char* e = std::getenv("GCAST_ONEPASS"); t.onepass = !(e && std::strcmp(e, "0") == 0); }
   t.split_tail = env_int("GCAST_SPLIT_TAIL", GC_SPLIT_TAIL_DEFAULT) != 0;
-  t.bf16_stream = env_int("GCAST_BF16_STREAM", GC_BF16_STREAM_DEFAULT) & 3;
+  t.bf16_stream = env_int("GCAST_BF16_STREAM", GC_BF16_STREAM_DEFAULT) != 0;
   t.wide_late = env_int("GCAST_WIDE_LATE", GC_WIDE_LATE_DEFAULT) != 0;
   return t;
 }
@@ -796,7 +796,7 @@ bool tuning_valid(const gc_tuning& t) {
          !(t.prio_other & ~3) && !(t.prio_stage & ~3) && t.helpers >= -1 && t.helpers <= 1 && b(t.helpers_small) &&
          t.helpers_edge >= 0 && t.helpers_edge <= 2 && t.helper_store >= 0 && t.helper_store <= 2 && t.helpers_min_rows >= 0 &&
          b(t.wide) && !(t.wide_edges & ~3) && (t.bf16_rows == 0 || t.bf16_rows == 64 || t.bf16_rows == 128) && b(t.tile_queue) &&
-         b(t.fuse) && b(t.onepass) && b(t.split_tail) && !(t.bf16_stream & ~3) && b(t.wide_late);
+         b(t.fuse) && b(t.onepass) && b(t.split_tail) && b(t.bf16_stream) && b(t.wide_late);
 }
 int half_grid_cap() { return tuning().grid_cap; }
 bool half_tile_xcd() { return tuning().tile_map_xcd != 0; }
@@ -830,6 +830,7 @@ inline bool tile_queue_pays(const gc_rowmlp_desc& d, int tiles, int grid) {
 
 template <int MODE, int ONEPASS, int LATE = 0>
 int launch_rowmlp_half_w(const gc_rowmlp_desc& d, hipStream_t s);
+inline void apply_prio(gc_rowmlp_desc& dd, bool bf16);
 
 template <int MODE, int ONEPASS = 0>
 int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
@@ -843,13 +844,41 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
     const bool wide_edge = d.seg && !(d.flags & (GC_WG_HELPERS | GC_WG_NO_HELPERS)) &&
                            (tuning().wide_edges & (ONEPASS != 0 ? 1 : 2)) && tuning().helpers != 1 &&
                            (d.n_rows + kHRows - 1) / kHRows >= GC_WIDE_EDGE_MIN_TILES;
+    // GC_LATE_ADDENDS (round 6): a two-pass edge update that adds its gathered rows when the hidden layer is formed -- an fp32
+    // ASSOCIATION of its own, so it is a property of the launch: asked for by the flag (honoured by the wide and the
+    // four-wave form, same bits in both), and by gc_tuning.wide_late for the launches the wide_edges RULE puts into the
+    // wide form (where the gather has nothing to run under: -1.5 % of the step).  A launch pinned to a form by its own
+    // flags keeps the association it asks for.
+    const bool late_shape = ONEPASS == 0 && d.seg && d.g0 && !d.d && d.k0 + d.k1 > 0;
+    const bool late = late_shape && ((d.flags & GC_LATE_ADDENDS) || (wide_edge && !(d.flags & GC_WG_WIDE) && tuning().wide_late));
     if ((d.flags & GC_WG_WIDE) || wide_edge) {
-      // gc_tuning.wide_late (round 6): a wide two-pass edge update adds its gathered rows when the hidden layer is formed
       if constexpr (ONEPASS == 0) {
-        if ((tuning().wide_late || (d.flags & GC_LATE_ADDENDS)) && d.seg && d.g0 && !d.d && d.k0 + d.k1 > 0)
-          return launch_rowmlp_half_w<MODE, ONEPASS, 1>(d, s);
+        if (late) return launch_rowmlp_half_w<MODE, ONEPASS, 1>(d, s);
       }
       return launch_rowmlp_half_w<MODE, ONEPASS>(d, s);
+    }
+    if constexpr (ONEPASS == 0) {
+      if (late) {               // (the four-wave form of the same association: what the tests compare the wide form with)
+        static bool attr_set = false;
+        const size_t lds = kHLdsFloats * sizeof(float);
+        if (!attr_set) {
+          const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowmlp16h_kernel<MODE, 0, 1>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e != hipSuccess) {
+            std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+            return GC_ELAUNCH;
+          }
+          attr_set = true;
+        }
+        const int tiles = (d.n_rows + kHRows - 1) / kHRows;
+        const int cap = half_grid_cap();
+        const int grid = tiles < cap ? tiles : cap;
+        gc_rowmlp_desc dd = d;
+        if (!tile_queue_pays(dd, tiles, grid)) dd.tile_queue = nullptr;
+        apply_prio(dd);
+        hipLaunchKernelGGL((rowmlp16h_kernel<MODE, 0, 1>), dim3(grid), dim3(256), lds, s, dd);
+        return check_launch("rowmlp16h_kernel");
+      }
     }
   }
   // Round 6: a node-side launch of 513 .. 768 tiles (the 0.25 deg processor's node updates: 641) is 1.6 rounds of
@@ -1031,12 +1060,8 @@ int launch_rowmlp_bf16(const gc_rowmlp_desc& d, hipStream_t s) {
   // Round 6 (gc_tuning.bf16_stream): an edge update without a layer-1 GEMM -- the whole first layer folded into addend
   // rows -- forms every K step's hidden pair on the fly instead of gathering up front (rowmlp_bf16.inc: STREAM).
   if constexpr (!F32ROWS) {
-    if ((tuning().bf16_stream & 1) && d.k0 + d.k1 == 0 && d.g0 && d.n_chain == 0)
+    if (tuning().bf16_stream && d.k0 + d.k1 == 0 && d.g0 && d.n_chain == 0)
       return wide ? launch_rowmlp_bf16<F32ROWS, 8, 1>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, 1>(d, s);
-    // ... and one WITH a layer-1 GEMM adds its gathered rows when the hidden layer is formed (GC_LATE_ADDENDS: its own
-    // instantiation of the kernel)
-    if (((tuning().bf16_stream & 2) || (d.flags & GC_LATE_ADDENDS)) && d.k0 + d.k1 > 0 && d.g0 && !d.d)
-      return wide ? launch_rowmlp_bf16<F32ROWS, 8, 2>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, 2>(d, s);
   }
   return wide ? launch_rowmlp_bf16<F32ROWS, 8, 0>(d, s) : launch_rowmlp_bf16<F32ROWS, 4, 0>(d, s);
 }

@@ -114,13 +114,13 @@ enum gc_precision { GC_PREC_F32 = 0, GC_PREC_F16X3 = 1, GC_PREC_BF16_IMAGE = 2 /
                                   * CU -- 128 rows against one weight ring, half the L2 -> LDS stream per row
                                   * (csrc/rowmlp_half.inc: rowmlp16w_kernel).  Same bits.  Round 6: also launches with a
                                   * segment-sum and the one-pass (GC_W2_NATURAL) ones.  Ignored in other modes. */
-#define GC_LATE_ADDENDS 512      /* (also honoured by the GC_PREC_F16X3 wide form: gc_tuning.wide_late)
-                                  * GC_PREC_BF16 launches WITH a layer-1 GEMM whose addends are gathered rows (the processor's edge
-                                  * update): the gathered rows are added when the hidden layer is formed -- loads pipelined
-                                  * four pairs ahead under the swish bursts -- instead of in a burst in front of layer 1.
-                                  * (b1 + products) + g0 + g1 instead of (b1 + g0 + g1) + products: another fp32
-                                  * association in front of the SAME bfloat16 rounding, not the same bits.  Set by the
-                                  * launcher when gc_tuning.bf16_stream is on; ignored elsewhere. */
+#define GC_LATE_ADDENDS 512      /* GC_PREC_F16X3, two-pass GC_MODE_MLP_LN launches with a layer-1 GEMM and gathered addends (the
+                                  * processor's edge update): the gathered rows are added when the hidden layer is formed --
+                                  * loads pipelined three K steps ahead under the swish / split bursts -- instead of in a burst in
+                                  * front of layer 1: ((b1 + products) + g0) + g1 instead of (b1 + g0 + g1) + products, another
+                                  * fp32 ASSOCIATION (1e-7 apart).  Honoured by the four-wave and the wide form (the same bits
+                                  * in both); a launch with the flag does not run in the helper form.  gc_tuning.wide_late sets
+                                  * it on the launches the wide_edges rule puts into the wide form. */
 #define GC_WIDE_MIN_ROWS 262144   /* the plan asks for GC_WG_WIDE from this many rows on (>= 8 rounds of 256 128-row tiles:
                                   * below, the doubled tail costs more than the shared ring saves) */
 #define GC_TILE_QUEUE_ANY 128    /* gc_rowmlp_desc.tile_queue: hand the tiles out dynamically whenever the launch has more
@@ -517,13 +517,13 @@ typedef struct gc_tuning {
                             four-wave pairs whose second round leaves half the chip idle.  Measured (profiles/r06_s4_*): that
                             stage 2 % faster, the power-limited step unchanged -- default 0 */
   int bf16_stream;       /* GCAST_BF16_STREAM (round 6): GC_PREC_BF16 edge updates without a layer-1 GEMM form every K step's hidden
-                            pair on the fly from addend loads four K steps ahead instead of gathering up front (same bits); bit 1:
-                            those WITH a layer-1 GEMM add their gathered rows when the hidden layer is formed (GC_LATE_ADDENDS);
-                            0 .. 3, default 3 */
-  int wide_late;         /* GCAST_WIDE_LATE (round 6): a two-pass edge update in the WIDE form adds its gathered rows when the hidden
-                            layer is formed (GC_LATE_ADDENDS) instead of in a burst in front of layer 1 that nothing multiplies
-                            under in that form.  Another fp32 association: that launch is then not bit-identical to the
-                            four-wave kernel (1e-7).  0 | 1 */
+                            pair on the fly from addend loads four K steps ahead instead of gathering up front (same bits);
+                            default 1 */
+  int wide_late;         /* GCAST_WIDE_LATE (round 6): the two-pass edge updates that the wide_edges rule puts into the WIDE form carry
+                            GC_LATE_ADDENDS -- their gathered rows are added when the hidden layer is formed instead of in a burst
+                            in front of layer 1 that nothing multiplies under in that form (processor edge update -3.3 %, step
+                            -1.5 %).  Another fp32 association (1e-7), the same bits in every form that honours the flag.
+                            default 1 */
   int reserved[5];
 } gc_tuning;
 int gc_get_tuning(gc_tuning* out);
@@ -532,10 +532,10 @@ int gc_plan_get_tuning(const gc_plan* plan, gc_tuning* out);
 const char* gc_tuning_string(const gc_tuning* t);
 #define GC_WIDE_EDGE_MIN_TILES 4096   /* 64-row tiles: >= 8 rounds of 256 wide tiles */
 #ifndef GC_WIDE_LATE_DEFAULT
-#define GC_WIDE_LATE_DEFAULT 0        /* gc_tuning.wide_late of a process that does not set GCAST_WIDE_LATE */
+#define GC_WIDE_LATE_DEFAULT 1        /* gc_tuning.wide_late of a process that does not set GCAST_WIDE_LATE */
 #endif
 #ifndef GC_BF16_STREAM_DEFAULT
-#define GC_BF16_STREAM_DEFAULT 3      /* gc_tuning.bf16_stream of a process that does not set GCAST_BF16_STREAM */
+#define GC_BF16_STREAM_DEFAULT 1      /* gc_tuning.bf16_stream of a process that does not set GCAST_BF16_STREAM */
 #endif
 #ifndef GC_SPLIT_TAIL_DEFAULT
 #define GC_SPLIT_TAIL_DEFAULT 0       /* gc_tuning.split_tail of a process that does not set GCAST_SPLIT_TAIL */

@@ -90,5 +90,14 @@ case "$NAME" in
     bash scripts/session.sh bench-ab r06_s7 "GCAST_WIDE_LATE=0" "GCAST_WIDE_LATE=1" "GCAST_WIDE_LATE=0" "GCAST_WIDE_LATE=1"
     timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
     ;;
+  s8)
+    # Round-6 session 8: GC_LATE_ADDENDS as a property of the launch (four-wave and wide form: the same bits), gc_tuning.wide_late
+    # = 1 as the shipped default; the bf16 tier without its LATE variant (measured slower, removed).
+    timeout 1500 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_bf16_tier_gpu.py tests/test_step_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "late addends as a launch property"
+    grep "late addends" "$OUT/pytest.log" | cut -c1-200
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$OUT/smoke.log"
+    bash scripts/session.sh bench-ab r06_s8 "GCAST_WIDE_LATE=1" "GCAST_WIDE_LATE=0" "GCAST_WIDE_LATE=1" "GCAST_WIDE_LATE=0 GCAST_WIDE_EDGES=0"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

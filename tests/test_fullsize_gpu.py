@@ -65,6 +65,30 @@ def test_full_size_modes_agree(full):
   assert rel < 5e-6
 
 
+def test_full_size_forms_and_association(full):
+  """Round 6, at the headline size, where the launcher's rules actually apply: every edge update of >= 4096 tiles runs in
+  the WIDE form (gc_tuning.wide_edges = 3) and the two-pass ones among them add their gathered rows late
+  (gc_tuning.wide_late: another fp32 association).  With the association switched off the wide forms give the bits of
+  the round-5 pairs; the association itself moves the whole [1,038,240, 227] output by ~1e-7."""
+  from graphcast_amd import _native as nat
+  m, x = full["model"], full["x"]
+  y = full.get("y")
+  if y is None:
+    y = m.forward_grid_node_features(x).clone()
+  assert nat.get_tuning().wide_edges == 3 and nat.get_tuning().wide_late == 1
+  prev = nat.set_tuning(wide_late=0)
+  try:
+    y_wide = m.forward_grid_node_features(x).clone()
+    nat.set_tuning(wide_late=0, wide_edges=0)
+    y_pairs = m.forward_grid_node_features(x).clone()
+  finally:
+    nat.set_tuning(prev)
+  assert torch.equal(y_wide, y_pairs)                   # the wide forms of the edge updates: the four-wave kernel's bits
+  rel = float(torch.linalg.vector_norm((y - y_pairs).double()) / torch.linalg.vector_norm(y_pairs.double()))
+  print(f"0.25 deg: late addends in the wide processor edge updates vs the up-front association: rel-RMSE {rel:.2e}")
+  assert 0.0 < rel < 1e-6
+
+
 def test_full_size_batch_independence(full):
   m, x = full["model"], full["x"]
   xb = torch.cat([x, x.flip(0)], dim=1).contiguous()           # two different batch elements

@@ -831,14 +831,19 @@ def test_processor_edge_update_in_both_kernel_forms(dev, n_recv):
     got_e, got_agg = pipeline(flags, with_queue)
     assert torch.equal(got_e, ref_e), (flags, with_queue, float((got_e - ref_e).abs().max()))
     assert torch.equal(got_agg[torch.from_numpy(has).to(dev)], ref_agg[torch.from_numpy(has).to(dev)]), (flags, with_queue)
-  # round 6 (gc_tuning.wide_late / GC_LATE_ADDENDS; off by default): the wide form adding its gathered rows when the hidden
-  # layer is formed -- ((b1 + products) + g0) + g1 instead of (b1 + g0 + g1) + products: another fp32 association, so NOT the
-  # four-wave kernel's bits any more (1e-7), but repeatable, and as close to the float64 oracle as the other forms
-  late_e, late_agg = pipeline(nat.WG_WIDE | nat.LATE_ADDENDS, False)
-  again_e, again_agg = pipeline(nat.WG_WIDE | nat.LATE_ADDENDS | nat.TILE_QUEUE_ANY, True)
-  assert torch.equal(late_e, again_e) and torch.equal(late_agg[torch.from_numpy(has).to(dev)], again_agg[torch.from_numpy(has).to(dev)])
+  # round 6 (GC_LATE_ADDENDS; gc_tuning.wide_late sets it on the launches the wide_edges rule makes wide): the gathered rows
+  # added when the hidden layer is formed -- ((b1 + products) + g0) + g1 instead of (b1 + g0 + g1) + products: another fp32
+  # ASSOCIATION, so not the unflagged launch's bits (1e-7 apart) -- but the SAME bits in both forms that honour the flag
+  # (four-wave and wide; a flagged launch never runs in the helper form), statically walked and through the queue, and
+  # as close to the float64 oracle as the unflagged launch
+  late_e, late_agg = pipeline(nat.WG_NO_HELPERS | nat.LATE_ADDENDS, False)
+  for flags, with_queue in ((nat.WG_WIDE | nat.LATE_ADDENDS, False), (nat.WG_WIDE | nat.LATE_ADDENDS | nat.TILE_QUEUE_ANY, True),
+                            (nat.LATE_ADDENDS | nat.TILE_QUEUE_ANY, True), (nat.WG_HELPERS | nat.LATE_ADDENDS, False)):
+    again_e, again_agg = pipeline(flags, with_queue)
+    assert torch.equal(late_e, again_e), (flags, with_queue)
+    assert torch.equal(late_agg[torch.from_numpy(has).to(dev)], again_agg[torch.from_numpy(has).to(dev)]), (flags, with_queue)
   assert not torch.equal(late_e, ref_e)
   assert float((late_e - ref_e).norm() / ref_e.norm()) < 5e-7
-  assert_close(late_e.cpu().numpy()[ok], (p["a0"].astype(np.float64) + e_new)[ok], "processor edge rows (wide form, late addends)")
+  assert_close(late_e.cpu().numpy()[ok], (p["a0"].astype(np.float64) + e_new)[ok], "processor edge rows (late addends)")
   got = late_agg.cpu().numpy()
   assert np.linalg.norm(got[has] - want[has]) <= 2 * REL_RMSE_TOL[_PREC] * np.linalg.norm(want[has])
