@@ -415,8 +415,7 @@ def main():
             "batch_per_gpu": 1},
         "roofline": {
             "bound": "mfma",
-            "kernel": f"{ {'f16x3': 'rowmlp16h_kernel', 'f32': 'rowmlp_kernel', 'bf16': 'rowmlpbf_kernel'}[precision] }"
-                      f"<MLP_LN> stage {dominant}",
+            "kernel": f"{dominant_kernel_name(precision, dominant, dom, nat.get_tuning())} stage {dominant}",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,
             "mfma_flops_per_algorithmic_flop": issue,
@@ -511,6 +510,25 @@ class _PowerPoll:
       return {"unavailable": sorted({e for s in self._samples for e in s.get("errors", [])})[:2]}
     return {"socket_w_median": pw[len(pw) // 2], "socket_w_max": pw[-1], "sclk_mhz_median": ck[len(ck) // 2] if ck else None,
             "samples": len(pw), "board_power_w": 1400, "tool": "amd-smi metric --power --clock (scripts/power_probe.py)"}
+
+
+def dominant_kernel_name(precision, stage, dom, tuning):
+  """The kernel the dominant stage's launches run as (what a rocprofv3 kernel trace of this command shows): the form follows
+  the launcher's rules (csrc/gcast.hip: launch_rowmlp_half) -- since round 6 every edge update of >= 4096 tiles runs in the
+  wide form, the two-pass ones with GC_LATE_ADDENDS."""
+  if precision == "f32":
+    return "rowmlp_kernel<MLP_LN>"
+  if precision == "bf16":
+    return "rowmlpbf_kernel<., 4, 0> (64-row workgroups, two per CU)"
+  if stage in ("proc_edge", "enc_edge", "dec_edge"):
+    onepass = stage != "proc_edge"
+    if tuning.wide_edges & (1 if onepass else 2):
+      late = (not onepass) and tuning.wide_late
+      return ("rowmlp16w_kernel<MLP_LN, " + ("3" if stage == "dec_edge" else "2" if onepass else "0") + (", 1> (wide form, GC_LATE_ADDENDS)" if late else ", 0> (wide form)"))
+    return "rowmlp16h_kernel<MLP_LN> (pairs of four-wave workgroups)"
+  if stage in ("enc_embed_grid", "enc_node_grid", "dec_node") and tuning.wide:
+    return "rowmlp16w_kernel<MLP_LN, 0, 0> (wide form)"
+  return "rowmlp16h_kernel<MLP_LN>"
 
 
 def stage_table(engine, x, y, iters):
@@ -759,7 +777,7 @@ def single_process_main(args):
                  "devices": devices, "distinct_devices": len(set(devices)), "batch_per_gpu": 1,
                  "note": (None if len(set(devices)) == len(devices) else
                           "engines share a device: `value` is that device's rate with several engines resident, not a scaling point")},
-      "roofline": {"bound": "mfma", "kernel": f"rowmlp16h_kernel<MLP_LN> stage {dominant} (engine 0, timed alone)",
+      "roofline": {"bound": "mfma", "kernel": f"{dominant_kernel_name(precision, dominant, dom, nat.get_tuning())} stage {dominant} (engine 0, timed alone)",
                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                    "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                    "stages": stages_summary(per_stage, peak)},
