@@ -115,6 +115,7 @@ def main():
     d.scratch = scratch.data_ptr()
     if use_queue and layout == nat.LAYOUT_HALF:
       d.tile_queue = queue.data_ptr()
+    d.flags |= int(os.environ.get("PROBE_FLAGS", "0"))        # e.g. 256 = GC_WG_WIDE: every shape in the wide form
     return d
 
   def proc_edge(layout):
