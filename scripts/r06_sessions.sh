@@ -99,5 +99,16 @@ case "$NAME" in
     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$OUT/smoke.log"
     bash scripts/session.sh bench-ab r06_s8 "GCAST_WIDE_LATE=1" "GCAST_WIDE_LATE=0" "GCAST_WIDE_LATE=1" "GCAST_WIDE_LATE=0 GCAST_WIDE_EDGES=0"
     ;;
+  s9)
+    # Round-6 session 9: where a WIDE tile's time goes -- wave-0 phase traces (GC_H_TRACE profiling build) of the processor
+    # edge update in the pair form, the wide form and the wide form with late addends; of the one-pass decoder edge update
+    # and the grid node update in the wide form; and what the layer-1 row loads' memory latency costs in the wide form
+    # (the same GEMM-only launch on streamed rows / on 64 cached rows).
+    for F in 0 256 768; do
+      HALF_TRACE=1 PROBE_FLAGS=$F PROBE_SHAPES=proc_edge timeout 300 python -u scripts/half_probe.py --out "$OUT/trace_proc_edge_flags$F.json" 2>&1 | grep htrace | cut -c1-900
+    done
+    HALF_TRACE=1 PROBE_FLAGS=256 PROBE_SHAPES=dec_edge_onepass,node_grid timeout 300 python -u scripts/half_probe.py --out "$OUT/trace_wide_onepass_node.json" 2>&1 | grep htrace | cut -c1-900
+    PROBE_FLAGS=256 PROBE_SHAPES=gemm_only_mlp,gemm_only_cached_rows,node_grid timeout 300 python -u scripts/half_probe.py --rounds 2 --iters 10 --out "$OUT/probe_wide_rows.json" 2>&1 | grep -v amdgpu | cut -c1-500 | tail -4
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
