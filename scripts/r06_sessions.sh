@@ -110,5 +110,18 @@ case "$NAME" in
     HALF_TRACE=1 PROBE_FLAGS=256 PROBE_SHAPES=dec_edge_onepass,node_grid timeout 300 python -u scripts/half_probe.py --out "$OUT/trace_wide_onepass_node.json" 2>&1 | grep htrace | cut -c1-900
     PROBE_FLAGS=256 PROBE_SHAPES=gemm_only_mlp,gemm_only_cached_rows,node_grid timeout 300 python -u scripts/half_probe.py --rounds 2 --iters 10 --out "$OUT/probe_wide_rows.json" 2>&1 | grep -v amdgpu | cut -c1-500 | tail -4
     ;;
+  s10)
+    # Round-6 session 10: the epilogue of the late-addend kernels read from the disassembly -- no scratch reload (each one a
+    # full vmcnt drain) between a segment-sum scan's runs, between layer 2's passes, inside LayerNorm; receiver ids prefetched
+    # in the prologue; residual + store through the staged tile (full 1 KiB lines, scalar row bases); LDS barriers without
+    # the global fence; LayerNorm's sums as packed f4 operations.  Tests first, then same-session A/B against the library of
+    # commit e8bb181 (ab_libs/libgcast_r6head.so), then the wave-0 phase trace of the processor edge update.
+    timeout 1500 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_step_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "epilogue rewrite"
+    bash scripts/session.sh bench-ab r06_s10 "" "GCAST_LIB_PATH=ab_libs/libgcast_r6head.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_r6head.so"
+    for F in 256 768; do
+      HALF_TRACE=1 PROBE_FLAGS=$F PROBE_SHAPES=proc_edge timeout 300 python -u scripts/half_probe.py --out "$OUT/trace_proc_edge_flags$F.json" 2>&1 | grep htrace | cut -c1-900
+    done
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
