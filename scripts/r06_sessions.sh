@@ -123,5 +123,14 @@ case "$NAME" in
       HALF_TRACE=1 PROBE_FLAGS=$F PROBE_SHAPES=proc_edge timeout 300 python -u scripts/half_probe.py --out "$OUT/trace_proc_edge_flags$F.json" 2>&1 | grep htrace | cut -c1-900
     done
     ;;
+  s11)
+    # Round-6 session 11: the prologue of the two-pass launches -- both gather indices requested in front of the ring's first
+    # pieces (they were two dependent round trips, each behind a full drain), b1 from LDS for launches without a chain, the
+    # tile queue's atomic in front of the prologue's drain instead of at the top of the tile.  Tests, then A/B against the
+    # library of session s10 (commit 2e20a7b, ab_libs/libgcast_s10.so).
+    timeout 1500 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_step_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "prologue rewrite"
+    bash scripts/session.sh bench-ab r06_s11 "" "GCAST_LIB_PATH=ab_libs/libgcast_s10.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s10.so"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
