@@ -132,5 +132,12 @@ case "$NAME" in
     gate "$OUT/pytest.log" "prologue rewrite"
     bash scripts/session.sh bench-ab r06_s11 "" "GCAST_LIB_PATH=ab_libs/libgcast_s10.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s10.so"
     ;;
+  s12)
+    # Round-6 session 12: no thread-id value of the top of the tile used behind layer 1 (bias addresses of layer 2's and the
+    # chain's passes, chained stores, the row-owner epilogue: each was a scratch reload + ring drain).  Tests, A/B vs s11.
+    timeout 1500 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_step_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "fresh lane values behind layer 1"
+    bash scripts/session.sh bench-ab r06_s12 "" "GCAST_LIB_PATH=ab_libs/libgcast_s11.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s11.so"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
