@@ -139,5 +139,15 @@ case "$NAME" in
     gate "$OUT/pytest.log" "fresh lane values behind layer 1"
     bash scripts/session.sh bench-ab r06_s12 "" "GCAST_LIB_PATH=ab_libs/libgcast_s11.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s11.so"
     ;;
+  s13)
+    # Round-6 session 13: the bf16 tier's epilogue after the f16x3 kernels' (ids / flags prefetched in the prologue, ballot
+    # scan with scalar-base run stores, LDS barriers, packed LayerNorm sums, lane values formed where they are used).
+    # The tier's tests, then A/B of its step against the library of session s12.
+    timeout 1200 python -m pytest tests/test_bf16_tier_gpu.py tests/test_rowmlp_gpu.py tests/test_native_abi.py -m gpu -q -x --timeout=600 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "bf16 epilogue"
+    bash scripts/session.sh bench-ab r06_s13 --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 --precision bf16 -- \
+        "" "GCAST_LIB_PATH=ab_libs/libgcast_s12.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s12.so"
+    timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
