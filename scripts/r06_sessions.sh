@@ -149,5 +149,14 @@ case "$NAME" in
         "" "GCAST_LIB_PATH=ab_libs/libgcast_s12.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s12.so"
     timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
     ;;
+  s14)
+    # Round-6 session 14: bf16 tier -- the plain launch without a chain as an instantiation of its own (VAR 2: no spills),
+    # both gather indices requested at once.  The tier's tests, A/B against the library of session s13, whole-step tests.
+    timeout 1200 python -m pytest tests/test_bf16_tier_gpu.py tests/test_rowmlp_gpu.py tests/test_native_abi.py -m gpu -q -x --timeout=600 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "bf16 no-chain instantiation"
+    bash scripts/session.sh bench-ab r06_s14 --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 --precision bf16 -- \
+        "" "GCAST_LIB_PATH=ab_libs/libgcast_s13.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s13.so"
+    timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
