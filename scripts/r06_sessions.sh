@@ -158,5 +158,15 @@ case "$NAME" in
         "" "GCAST_LIB_PATH=ab_libs/libgcast_s13.so" "" "GCAST_LIB_PATH=ab_libs/libgcast_s13.so"
     timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py tests/test_rollout_gpu.py tests/test_partition_gpu.py -m gpu -q -x --timeout=600 > "$OUT/pytest2.log" 2>&1; echo "pytest2 rc=$?"; tail -3 "$OUT/pytest2.log" | cut -c1-400
     ;;
+  s15)
+    # Round-6 session 15: the small sizes on the library of session s14 -- the 1 deg step and an emulated 8-way rank, each
+    # with the shipped form rules and with the processor edge update pinned away from the helper form (GCAST_HELPERS_EDGE=0:
+    # four-wave pairs), and against the library of commit e8bb181.
+    for E in "" "GCAST_HELPERS_EDGE=0" "GCAST_LIB_PATH=ab_libs/libgcast_r6head.so"; do
+      tag=$(echo "${E:-default}" | tr ' =/' '__-')
+      env $E timeout 600 python bench.py --config 1deg_13L_M5 --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_1deg_$tag.json" 2> "$OUT/bench_1deg_$tag.err"; echo "1deg [$E] rc=$?"; show "$OUT/bench_1deg_$tag.json"
+      env $E timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8_$tag.json" 2>&1 | tail -1 | cut -c1-600
+    done
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
