@@ -125,7 +125,7 @@ class Tuning(ctypes.Structure):
   _fields_ = [(name, ctypes.c_int) for name in (
       "grid_cap", "tile_map_xcd", "prio_set", "prio_gemm", "prio_other", "prio_stage", "helpers", "helpers_small",
       "helpers_edge", "helper_store", "helpers_min_rows", "wide", "wide_edges", "bf16_rows", "tile_queue", "fuse",
-      "onepass", "split_tail", "bf16_stream", "wide_late")] + [("reserved", ctypes.c_int * 5)]
+      "onepass", "split_tail", "bf16_stream", "wide_late", "split_edges")] + [("reserved", ctypes.c_int * 4)]
 
   def as_dict(self):
     return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}

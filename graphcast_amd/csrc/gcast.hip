@@ -783,6 +783,7 @@ gc_tuning tuning_from_env() {
   t.split_tail = env_int("GCAST_SPLIT_TAIL", GC_SPLIT_TAIL_DEFAULT) != 0;
   t.bf16_stream = env_int("GCAST_BF16_STREAM", GC_BF16_STREAM_DEFAULT) != 0;
   t.wide_late = env_int("GCAST_WIDE_LATE", GC_WIDE_LATE_DEFAULT) != 0;
+  t.split_edges = env_int("GCAST_SPLIT_EDGES", GC_SPLIT_EDGES_DEFAULT) != 0;
   return t;
 }
 gc_tuning& tuning_mut() {
@@ -796,7 +797,7 @@ bool tuning_valid(const gc_tuning& t) {
          !(t.prio_other & ~3) && !(t.prio_stage & ~3) && t.helpers >= -1 && t.helpers <= 1 && b(t.helpers_small) &&
          t.helpers_edge >= 0 && t.helpers_edge <= 2 && t.helper_store >= 0 && t.helper_store <= 2 && t.helpers_min_rows >= 0 &&
          b(t.wide) && !(t.wide_edges & ~3) && (t.bf16_rows == 0 || t.bf16_rows == 64 || t.bf16_rows == 128) && b(t.tile_queue) &&
-         b(t.fuse) && b(t.onepass) && b(t.split_tail) && b(t.bf16_stream) && b(t.wide_late);
+         b(t.fuse) && b(t.onepass) && b(t.split_tail) && b(t.bf16_stream) && b(t.wide_late) && b(t.split_edges);
 }
 int half_grid_cap() { return tuning().grid_cap; }
 bool half_tile_xcd() { return tuning().tile_map_xcd != 0; }
@@ -840,6 +841,45 @@ int launch_rowmlp_half(const gc_rowmlp_desc& d, hipStream_t s) {
   // Round 6: the form also takes launches with a segment-sum (two 64-row sub-tiles per workgroup) and the one-pass edge
   // updates; gc_tuning.wide_edges asks for it on edge updates of at least GC_WIDE_EDGE_MIN_TILES tiles that do not pin
   // another form (bit 0: one-pass, bit 1: two-pass).
+  // Round 6 (gc_tuning.split_edges): the processor's edge update of a SMALL graph -- 1 deg: 1,280 tiles, a rank of the
+  // 8-way partition at 0.25 deg: 649 -- sits between the sizes the rules below were measured for: in the helper form it
+  // is ceil(tiles / 256) rounds of one 64-row tile per CU (64 us each), in the wide form ceil(tiles / 512) rounds of
+  // one 128-row tile per CU (104 us each: fewer joules AND less time per row, but a last round that is mostly empty).
+  // Hence: every FULL round of 256 wide tiles in the wide form, and what is left -- if it is at most one tile per CU --
+  // as a second launch in the helper form, the faster form of a lone tile (section 9.7); a remainder of more than 256
+  // tiles is a wide round of its own.  Tiles are independent (a tile's outputs, straddle partials included, are
+  // addressed by the tile) and both forms give the same bits as the four-wave kernel: nothing changes in the results.
+  // Applies to launches of the shape the helpers_edge rule takes (two-pass, b1 + g0 + g1, segment-sum, rows stored)
+  // that pin no form, above 512 tiles and below the wide_edges rule's GC_WIDE_EDGE_MIN_TILES.
+  // MEASURED (profiles/r06_s16_*, same session, alternating): slower -- 1 deg step 8.38 / 8.39 against 8.09 / 8.09 ms, an
+  // emulated 8-way rank 8.58 / 8.57 against 8.25 / 8.28 ms; the launch itself 5.13 against 5.08 ms per 1 deg step: a wide
+  // tile of this launch WITHOUT late addends is no faster per row than two helper-form tiles, and the second launch
+  // adds its own fill and drain.  Off by default (gc_tuning.split_edges = 0); kept as the measured alternative.
+  if constexpr (MODE == GC_MODE_MLP_LN && ONEPASS == 0) {
+    const gc_tuning& T = tuning();
+    const int t64 = (d.n_rows + kHRows - 1) / kHRows;
+    if (T.split_edges && T.helpers == -1 && T.helpers_edge == 1 && (T.wide_edges & 2) && d.seg && d.out && d.g0 && d.g1 &&
+        !d.d && d.b1 && d.k0 + d.k1 > 0 && !(d.flags & (GC_WG_WIDE | GC_WG_HELPERS | GC_WG_NO_HELPERS | GC_LATE_ADDENDS)) &&
+        t64 > GC_SCRATCH_SLOTS && t64 < GC_WIDE_EDGE_MIN_TILES && d.n_rows % kHRows == 0) {
+      const int head_tiles = t64 / GC_SCRATCH_SLOTS * GC_SCRATCH_SLOTS, tail_tiles = t64 - head_tiles;
+      gc_rowmlp_desc head = d;
+      head.flags |= GC_WG_WIDE;
+      if (tail_tiles == 0 || tail_tiles > GC_SCRATCH_SLOTS / 2) return launch_rowmlp_half_w<MODE, ONEPASS>(head, s);
+      const int head_rows = head_tiles * kHRows;
+      gc_rowmlp_desc tail = d;
+      head.n_rows = head_rows;
+      tail.n_rows = d.n_rows - head_rows;
+      tail.flags |= GC_WG_HELPERS;
+      auto rows = [&](const float* p, int ld) { return p ? p + (size_t)head_rows * ld : p; };
+      tail.a0 = rows(d.a0, d.lda0); tail.a1 = rows(d.a1, d.lda1);
+      tail.res = rows(d.res, d.ldres); tail.out = const_cast<float*>(rows(d.out, d.ldo));
+      tail.idx0 = d.idx0 + head_rows; tail.idx1 = d.idx1 + head_rows;
+      tail.seg = d.seg + head_rows; tail.tile_flags = d.tile_flags + head_tiles;
+      if (d.partial) tail.partial = d.partial + (size_t)2 * head_tiles * kD;
+      if (const int rc = launch_rowmlp_half_w<MODE, ONEPASS>(head, s)) return rc;
+      return launch_rowmlp_half_d<MODE, ONEPASS>(tail, s);
+    }
+  }
   if constexpr (MODE == GC_MODE_MLP_LN) {
     const bool wide_edge = d.seg && !(d.flags & (GC_WG_HELPERS | GC_WG_NO_HELPERS)) &&
                            (tuning().wide_edges & (ONEPASS != 0 ? 1 : 2)) && tuning().helpers != 1 &&
@@ -1414,10 +1454,10 @@ const char* gc_tuning_string(const gc_tuning* tp) {
   const gc_tuning& t = tp ? *tp : tuning();
   std::snprintf(buf, sizeof(buf),
                 "grid_cap=%d;tile_map=%s;prio=%d,%d,%d%s;helpers=%d;helpers_small=%d;helpers_edge=%d;helper_store=%d;"
-                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d;split_tail=%d;bf16_stream=%d;wide_late=%d",
+                "helpers_min_rows=%d;wide=%d;wide_edges=%d;bf16_rows=%d;tile_queue=%d;fuse=%d;onepass=%d;split_tail=%d;bf16_stream=%d;wide_late=%d;split_edges=%d",
                 t.grid_cap, t.tile_map_xcd ? "xcd" : "rr", t.prio_gemm, t.prio_other, t.prio_stage, t.prio_set ? "(set)" : "",
                 t.helpers, t.helpers_small, t.helpers_edge, t.helper_store, t.helpers_min_rows, t.wide, t.wide_edges, t.bf16_rows,
-                t.tile_queue, t.fuse, t.onepass, t.split_tail, t.bf16_stream, t.wide_late);
+                t.tile_queue, t.fuse, t.onepass, t.split_tail, t.bf16_stream, t.wide_late, t.split_edges);
   return buf;
 }
 

@@ -170,12 +170,67 @@ def plan(graphs: dict, grid_lon: np.ndarray, mesh_lon: np.ndarray, n_parts: int,
 class LocalExchanger:
   """All P ranks live in this process (emulation on one GPU / CPU): halo rows are copied
   directly between the ranks' tensors.  ``tensors[q]`` is rank q's row table
-  ``[owned_q + halo_q, 512]``; the owned prefix is valid on entry, the halo suffix on exit."""
+  ``[owned_q + halo_q, 512]``; the owned prefix is valid on entry, the halo suffix on exit.
+
+  An exchange is, per rank, what ``DistExchanger`` does on a real rank -- ONE packing ``index_select`` of the rows it
+  sends (all destinations, in destination order) and ONE landing of the rows it receives in its contiguous halo
+  suffix (here a second ``index_select`` out of the P ranks' packed send buffers, which stand in for the wire): 2 P
+  device launches per exchange, index tensors resident on the device.  (Until round 6 this walked the P x P pairs
+  with a host-built index tensor each -- 18 exchanges cost 21 ms of mostly host time per emulated 8-way step,
+  2.7 ms "per rank" that no rank of a real run spends; ``profiles/r06_s15_partition8_*``.)"""
 
   def __init__(self, plans: Sequence[HaloPlan], n_owned: Sequence[int]):
     self.plans, self.n_owned = list(plans), list(n_owned)
+    n_parts = len(self.plans)
+    as64 = lambda a: np.asarray(a, dtype=np.int64).reshape(-1)
+    # rank q's packed send buffer = its rows for destination 0 | 1 | ... ; the P buffers back to back form the "wire"
+    self._send_index = [np.concatenate([as64(pl.send_local[dst]) for dst in range(n_parts)]) if n_parts else as64([])
+                        for pl in self.plans]
+    starts = np.concatenate([[0], np.cumsum([len(i) for i in self._send_index])]).astype(np.int64)
+    self._send_start, self._wire_rows = starts, int(starts[-1])
+    # where on the wire the block (src -> dst) sits; a destination's halo suffix is those blocks in source order
+    block = [[int(starts[src] + sum(len(self.plans[src].send_local[d]) for d in range(dst))) for dst in range(n_parts)]
+             for src in range(n_parts)]
+    self._recv_index = [np.concatenate([block[src][dst] + np.arange(len(self.plans[src].send_local[dst]), dtype=np.int64)
+                                        for src in range(n_parts)]) if n_parts else as64([]) for dst in range(n_parts)]
+    self._dev = {}            # device -> (send index tensors, receive index tensors)
+    self._wire = {}           # (device, dtype, columns) -> the packed send buffers
+
+  def _indices(self, device):
+    import torch
+    key = str(device)
+    if key not in self._dev:
+      self._dev[key] = ([torch.as_tensor(i, device=device) for i in self._send_index],
+                        [torch.as_tensor(i, device=device) for i in self._recv_index])
+    return self._dev[key]
 
   def exchange(self, tensors):
+    import torch
+    if self._wire_rows == 0:
+      return
+    device = tensors[0].device
+    if any(t.device != device for t in tensors):          # ranks on several devices: pair by pair
+      return self._exchange_pairs(tensors)
+    send_idx, recv_idx = self._indices(device)
+    shape, dtype = tuple(tensors[0].shape[1:]), tensors[0].dtype
+    key = (str(device), dtype, shape)
+    if key not in self._wire:
+      self._wire[key] = torch.empty((self._wire_rows,) + shape, dtype=dtype, device=device)
+    wire = self._wire[key]
+    for src, t in enumerate(tensors):
+      a, b = int(self._send_start[src]), int(self._send_start[src + 1])
+      if b > a:
+        torch.index_select(t, 0, send_idx[src], out=wire[a:b])
+    for dst, t in enumerate(tensors):
+      n = len(self._recv_index[dst])
+      if n:
+        halo = t[self.n_owned[dst]:self.n_owned[dst] + n]
+        if halo.is_contiguous():
+          torch.index_select(wire, 0, recv_idx[dst], out=halo)
+        else:
+          halo.copy_(wire.index_select(0, recv_idx[dst]))
+
+  def _exchange_pairs(self, tensors):
     import torch
     n_parts = len(self.plans)
     for dst in range(n_parts):
@@ -255,6 +310,7 @@ class EmulatedPartitionedStep:
     self.n_grid = int(graphs["n_grid"])
     self.c_out = c_out
     self.exchanges_per_call = 0
+    self._owned_dev = {}
     # (rounds 3-4 could split every edge update into sender-local and halo-sender launches and run the exchange on a
     #  second stream under the first -- GCAST_OVERLAP=1.  Retired in round 5 on the measurements: the 18 extra small
     #  launches + joins cost 1.6 ms per rank at 8-way (profiles/r03_s9_*) against 0.47 ms for ALL 18 exchanges of a
@@ -263,7 +319,8 @@ class EmulatedPartitionedStep:
 
   def forward(self, x):
     import torch
-    xs = [x[torch.as_tensor(r.grid_owned, device=x.device)].contiguous() for r in self.ranks]
+    owned = self._owned_rows(x.device)
+    xs = [x.index_select(0, o) for o in owned]
     bound = [e.segments(xl) for e, xl in zip(self.engines, xs)]
     n_seg = len(bound[0][1])
     # (engine.segments: one segment per cut, so the structure does not depend on a rank's own split decisions)
@@ -278,9 +335,17 @@ class EmulatedPartitionedStep:
           self.exchanges_per_call += 1
           self.exchangers[name].exchange([e.halo_table(name) for e in self.engines])
     y = torch.empty((self.n_grid, x.shape[1], self.c_out), dtype=torch.float32, device=x.device)
-    for r, (yl, _) in zip(self.ranks, bound):
-      y[torch.as_tensor(r.grid_owned, device=x.device)] = yl
+    for o, (yl, _) in zip(owned, bound):
+      y.index_copy_(0, o, yl)
     return y
+
+  def _owned_rows(self, device):
+    """Every rank's owned grid rows as index tensors resident on `device` (built once: a real rank holds its rows)."""
+    import torch
+    key = str(device)
+    if key not in self._owned_dev:
+      self._owned_dev[key] = [torch.as_tensor(r.grid_owned, dtype=torch.int64, device=device) for r in self.ranks]
+    return self._owned_dev[key]
 
   __call__ = forward
 

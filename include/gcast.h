@@ -524,7 +524,13 @@ typedef struct gc_tuning {
                             in front of layer 1 that nothing multiplies under in that form (processor edge update -3.3 %, step
                             -1.5 %).  Another fp32 association (1e-7), the same bits in every form that honours the flag.
                             default 1 */
-  int reserved[5];
+  int split_edges;       /* GCAST_SPLIT_EDGES (round 6): the processor's two-pass edge update of 513 .. GC_WIDE_EDGE_MIN_TILES - 1 tiles
+                            (the 1 deg model: 1,280; a rank of the 8-way partition at 0.25 deg: 649) runs its full rounds of 256
+                            wide tiles in the WIDE form and a remainder of at most one tile per CU as a second launch in the
+                            helper form (a bigger remainder: a wide round of its own) instead of ceil(tiles / 256) rounds of the
+                            helper form.  The same bits (every form of a launch without GC_LATE_ADDENDS gives them).  Measured SLOWER
+                            (profiles/r06_s16_*: 1 deg step 8.38 against 8.09 ms, an 8-way rank 8.58 against 8.25 ms): default 0 */
+  int reserved[4];
 } gc_tuning;
 int gc_get_tuning(gc_tuning* out);
 int gc_set_tuning(const gc_tuning* t);          /* GC_EINVAL (and no change) for a value outside its range */
@@ -536,6 +542,9 @@ const char* gc_tuning_string(const gc_tuning* t);
 #endif
 #ifndef GC_BF16_STREAM_DEFAULT
 #define GC_BF16_STREAM_DEFAULT 1      /* gc_tuning.bf16_stream of a process that does not set GCAST_BF16_STREAM */
+#endif
+#ifndef GC_SPLIT_EDGES_DEFAULT
+#define GC_SPLIT_EDGES_DEFAULT 0      /* gc_tuning.split_edges of a process that does not set GCAST_SPLIT_EDGES */
 #endif
 #ifndef GC_SPLIT_TAIL_DEFAULT
 #define GC_SPLIT_TAIL_DEFAULT 0       /* gc_tuning.split_tail of a process that does not set GCAST_SPLIT_TAIL */

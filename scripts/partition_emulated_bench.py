@@ -70,12 +70,25 @@ def main():
       step.exchangers["mesh"].exchange(tables["mesh"])
     step.exchangers["m2g"].exchange(tables["m2g"])
   ms_exchange = timed(exchanges_only)
+  # the emulation's own shuffle of the global input into the ranks' rows and of their outputs back (a real rank holds its rows)
+  owned = step._owned_rows(x.device)
+  y_parts = [y.index_select(0, o) for o in owned]
+  def shuffle_only():
+    for o in owned:
+      x.index_select(0, o)
+    for o, yl in zip(owned, y_parts):
+      y.index_copy_(0, o, yl)
+  ms_shuffle = timed(shuffle_only)
   out = {
       "config": f"GraphCast {args.config}, {args.parts} parts ({'octants' if args.parts == 8 else 'hemispheres / quadrants' if args.parts in (2, 4) else 'longitude bands'}), receiver-owned edges",
       "rel_diff_vs_unpartitioned": rel, "exchanges_per_step": step.exchanges_per_call,
       "ms_unpartitioned_step": ms_full, "ms_sum_of_all_ranks_emulated_on_one_gpu": ms_part,
       "ms_per_rank_if_perfectly_parallel": ms_part / args.parts,
       "ms_all_exchanges_alone_all_ranks": ms_exchange,
+      "ms_emulation_input_output_shuffle_all_ranks": ms_shuffle,
+      "ms_per_rank_local_launches_only": (ms_part - ms_exchange - ms_shuffle) / args.parts,
+      "exchange_form": "per rank one packing index_select + one landing index_select (LocalExchanger, round 6); "
+                       "a real rank: index_select + all_to_all_single (bench.py --mode partition: roofline.exchange)",
       "grid_rows_per_rank": rows(lambda r: r.n_grid_owned), "mesh_rows_per_rank": rows(lambda r: r.n_mesh_owned),
       "edges_per_rank": {k: rows(lambda r, k=k: len(r.graphs[k]["senders"])) for k in ("g2m", "mesh", "m2g")},
       "halo_rows_per_rank": {"g2m_grid_rows": rows(lambda r: len(r.halo_g2m.halo_global)),

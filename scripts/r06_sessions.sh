@@ -168,5 +168,21 @@ case "$NAME" in
       env $E timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8_$tag.json" 2>&1 | tail -1 | cut -c1-600
     done
     ;;
+  s16)
+    # Round-6 session 16: gc_tuning.split_edges (the small graphs' processor edge update: full rounds of 256 wide tiles in the
+    # wide form + a helper-form launch for a remainder of at most one tile per CU) and the emulated partition's exchange as
+    # what a rank does (one packing + one landing index_select per rank and exchange, indices resident).  Tests, then the
+    # 1 deg step and an emulated 8-way rank with the rule on / off, alternating; one headline-size line for reference.
+    if [ "${SKIP_TESTS:-0}" != "1" ]; then
+      timeout 1500 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_partition_gpu.py tests/test_step_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+      gate "$OUT/pytest.log" "split_edges / LocalExchanger"
+    fi
+    for E in "" "GCAST_SPLIT_EDGES=0" "" "GCAST_SPLIT_EDGES=0"; do
+      i=$((${i:-0} + 1)); tag=$(echo "${E:-default}" | tr ' =/' '__-')
+      env $E timeout 600 python bench.py --config 1deg_13L_M5 --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_1deg_${i}_$tag.json" 2> "$OUT/bench_1deg_${i}_$tag.err"; echo "1deg [$E] rc=$?"; show "$OUT/bench_1deg_${i}_$tag.json"
+      env $E timeout 600 python scripts/partition_emulated_bench.py --parts 8 --out "$OUT/partition8_${i}_$tag.json" 2>&1 | tail -1 | cut -c1-900
+    done
+    timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"; echo "full rc=$?"; show "$OUT/bench_full.json"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac

@@ -57,11 +57,11 @@ def test_tuning_is_one_struct_set_and_read_back(built):
   d = before.as_dict()
   assert set(d) == {"grid_cap", "tile_map_xcd", "prio_set", "prio_gemm", "prio_other", "prio_stage", "helpers",
                     "helpers_small", "helpers_edge", "helper_store", "helpers_min_rows", "wide", "wide_edges", "bf16_rows",
-                    "tile_queue", "fuse", "onepass", "split_tail", "bf16_stream", "wide_late"}
+                    "tile_queue", "fuse", "onepass", "split_tail", "bf16_stream", "wide_late", "split_edges"}
   if not any(k.startswith("GCAST_") for k in os.environ):      # the documented defaults of a process without overrides
     assert d == dict(grid_cap=512, tile_map_xcd=0, prio_set=0, prio_gemm=1, prio_other=0, prio_stage=0, helpers=-1,
                      helpers_small=1, helpers_edge=1, helper_store=2, helpers_min_rows=65536, wide=1,
-                     wide_edges=nat.WIDE_EDGES_DEFAULT, bf16_rows=0, tile_queue=1, fuse=1, onepass=1, split_tail=0, bf16_stream=1, wide_late=1)
+                     wide_edges=nat.WIDE_EDGES_DEFAULT, bf16_rows=0, tile_queue=1, fuse=1, onepass=1, split_tail=0, bf16_stream=1, wide_late=1, split_edges=0)
   try:
     prev = nat.set_tuning(grid_cap=256, helpers_edge=2, wide_edges=3, prio_gemm=2)
     assert bytes(prev) == bytes(before)

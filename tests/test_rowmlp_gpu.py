@@ -760,7 +760,7 @@ def test_small_launches_give_the_same_bits_in_both_kernel_forms(dev):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n_recv", [300, 9000])
+@pytest.mark.parametrize("n_recv", [300, 9000, 16500])
 def test_processor_edge_update_in_both_kernel_forms(dev, n_recv):
   """The processor's edge update as the step launches it from step 1 on (engine: proc_edge -- typed_graph_net.py:431-453
   after the pre-gather split): e.W_e (a layer-1 GEMM over the edge rows) + b1 + (h.W_s)[senders] + (h.W_r)[receivers]
@@ -831,6 +831,24 @@ def test_processor_edge_update_in_both_kernel_forms(dev, n_recv):
     got_e, got_agg = pipeline(flags, with_queue)
     assert torch.equal(got_e, ref_e), (flags, with_queue, float((got_e - ref_e).abs().max()))
     assert torch.equal(got_agg[torch.from_numpy(has).to(dev)], ref_agg[torch.from_numpy(has).to(dev)]), (flags, with_queue)
+  # round 6 (gc_tuning.split_edges): NO form pinned.  Above 512 tiles (n_recv 9000: 708 = 512 + 196; 16500: 1,295 = 1,024 +
+  # 271) the launcher runs the full rounds of 256 wide tiles in the wide form and a remainder of at most 256 tiles as a
+  # SECOND launch in the helper form (a bigger remainder: one wide launch) -- pointers, receiver ids, straddle flags and
+  # partial rows of the second launch offset by the first's tiles: the same bits, and the same with the rule off
+  if n_recv >= 9000:
+    assert pk.n_rows // 64 > 512 and (pk.n_rows // 64 % 512 <= 256) == (n_recv == 9000)
+  # (off by default: measured slower at the two sizes it was built for, profiles/r06_s16_*)
+  assert nat.get_tuning().helpers == -1
+  prev = nat.set_tuning(split_edges=1)
+  try:
+    for flags, with_queue in ((0, False), (nat.TILE_QUEUE_ANY, True)):
+      got_e, got_agg = pipeline(flags, with_queue)
+      assert torch.equal(got_e, ref_e), ("split_edges", flags, float((got_e - ref_e).abs().max()))
+      assert torch.equal(got_agg[torch.from_numpy(has).to(dev)], ref_agg[torch.from_numpy(has).to(dev)]), ("split_edges", flags)
+  finally:
+    nat.set_tuning(prev)
+  got_e, got_agg = pipeline(0, False)                   # (the rule off: the helpers_edge rule's form)
+  assert torch.equal(got_e, ref_e) and torch.equal(got_agg[torch.from_numpy(has).to(dev)], ref_agg[torch.from_numpy(has).to(dev)])
   # round 6 (GC_LATE_ADDENDS; gc_tuning.wide_late sets it on the launches the wide_edges rule makes wide): the gathered rows
   # added when the hidden layer is formed -- ((b1 + products) + g0) + g1 instead of (b1 + g0 + g1) + products: another fp32
   # ASSOCIATION, so not the unflagged launch's bits (1e-7 apart) -- but the SAME bits in both forms that honour the flag
