@@ -184,5 +184,14 @@ case "$NAME" in
     done
     timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"; echo "full rc=$?"; show "$OUT/bench_full.json"
     ;;
+  s17)
+    # Round-6 session 17: where the 1 deg step's time goes BETWEEN its kernels (session s16: a second launch per edge update
+    # cost the step 0.3 ms where the launch itself lost 0.05) -- a kernel trace of the 1 deg step and of an emulated 8-way
+    # step, gaps grouped by (previous kernel -> next kernel).
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OLDPWD/$OUT/prof_1deg" -o trace -- \
+        python "$OLDPWD/bench.py" --config 1deg_13L_M5 --steps 10 --warmup 2 --no-cpu-baseline --no-cross-check --rollout-steps 0 --op-timing-iters 1 > "$OLDPWD/$OUT/prof_1deg.json" 2> "$OLDPWD/$OUT/prof_1deg.err"); echo "rocprof rc=$?"
+    python scripts/kernel_gaps.py "$OUT/prof_1deg" --steps 4 --skip-tail 3 > "$OUT/kernel_gaps_1deg.json"; head -c 3000 "$OUT/kernel_gaps_1deg.json"
+    find "$OUT" -type f -size +8M -delete
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
