@@ -193,5 +193,47 @@ case "$NAME" in
     python scripts/kernel_gaps.py "$OUT/prof_1deg" --steps 4 --skip-tail 3 > "$OUT/kernel_gaps_1deg.json"; head -c 3000 "$OUT/kernel_gaps_1deg.json"
     find "$OUT" -type f -size +8M -delete
     ;;
+  s18)
+    # Round-6 session 18: the shipped library once more on another box -- a repeatability stress (the same step N times, every
+    # output bitwise against the first, other work beside every second repetition; both precisions, 1 deg and 0.25 deg) and the
+    # driver's step count with the round-end session's stamped counters attached to the line (roofline.traffic / pmc).
+    timeout 1200 python scripts/repeat_stress.py --reps 30 --out "$OUT/repeat_stress.json" 2>&1 | grep -v amdgpu.ids | tail -6; echo "stress rc=${PIPESTATUS[0]}"
+    timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_counters_attached.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; show "$OUT/bench_counters_attached.json"
+    python - "$OUT/bench_counters_attached.json" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = j["roofline"]
+print("traffic", r.get("traffic"), "frac", round(r["frac"], 4), "pmc", {k: v for k, v in (r.get("pmc") or {}).items() if k in ("mfma_busy_per_simd", "wave_waiting", "unavailable")})
+PY
+    ;;
+  s19)
+    # Round-6 session 19: session s18 found the bf16 tier NOT repeatable under the stress (4 of 120 runs at 1 deg, 5 of 30 at
+    # 0.25 deg differ from the first; the f16x3 kernels 0 of 150).  Which library introduced it: the round's libraries in turn
+    # (e8bb181 = before the second half, s12 = before the bf16 epilogue port, s13 = with it, s14 / in-tree = shipped), with
+    # and without the side work.
+    for L in "" ab_libs/libgcast_s13.so ab_libs/libgcast_s12.so ab_libs/libgcast_r6head.so; do
+      tag=$(basename "${L:-in-tree}" .so)
+      env ${L:+GCAST_LIB_PATH=$L} timeout 600 python scripts/repeat_stress.py --reps 40 --precisions bf16 --out "$OUT/stress_$tag.json" 2>&1 | grep -v amdgpu.ids | cut -c1-700 | tail -3
+    done
+    timeout 600 python scripts/repeat_stress.py --reps 40 --precisions bf16 --no-side-work --out "$OUT/stress_in-tree_no_side_work.json" 2>&1 | grep -v amdgpu.ids | cut -c1-700 | tail -3
+    ;;
+  s20)
+    # Round-6 session 20: which piece of the bf16 epilogue port (session s13) makes the tier non-repeatable at 0.25 deg --
+    # libraries of the shipped sources with one piece taken back each: __syncthreads() where the port uses the LDS-only
+    # barrier (GC_BF_SYNC=1), receiver ids / flags loaded between the segment-sum's barriers instead of in the prologue
+    # (GC_BF_SEGPRE=0), both.
+    for L in "" ${S20_LIBS:-ab_libs/libgcast_bf_sync.so ab_libs/libgcast_bf_segpre0.so ab_libs/libgcast_bf_both.so}; do
+      tag=$(basename "${L:-in-tree}" .so)
+      env ${L:+GCAST_LIB_PATH=$L} timeout 600 python scripts/repeat_stress.py --reps ${S20_REPS:-40} --precisions bf16 --configs 0.25deg_37L_M6 --no-side-work --out "$OUT/stress_$tag.json" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tail -2
+    done
+    ;;
+  s21)
+    # Round-6 session 21: the fix of the non-repeatable bf16 tier (the layer-1 loop's unconsumed row requests land before
+    # their registers are anyone else's; the same guard for the eight-wave kernel's multiplying waves) -- the tier's and the
+    # launch-level tests, the new repeatability test, then the stress at both sizes in both precisions.
+    timeout 1800 python -m pytest tests/test_native_abi.py tests/test_rowmlp_gpu.py tests/test_bf16_tier_gpu.py tests/test_step_gpu.py tests/test_repeatability_gpu.py -m gpu -q -x --timeout=900 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest.log" | cut -c1-400
+    gate "$OUT/pytest.log" "landing guards"
+    timeout 1200 python scripts/repeat_stress.py --reps 60 --out "$OUT/repeat_stress.json" 2>&1 | grep -v amdgpu.ids | cut -c1-300 | tail -6; echo "stress rc=${PIPESTATUS[0]}"
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
