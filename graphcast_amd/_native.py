@@ -133,7 +133,7 @@ class Tuning(ctypes.Structure):
 
 EXPORTS = ("gc_get_tuning", "gc_set_tuning", "gc_plan_get_tuning", "gc_tuning_string", "gc_plan_create", "gc_plan_workspace_bytes", "gc_step_forward", "gc_plan_check_range", "gc_plan_destroy",
            "gc_plan_program", "gc_plan_tensor",
-           "gc_host_pack_weight", "gc_host_pack_edges", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_add_rows", "gc_prep_grid_input", "gc_prep_grid_tail",
+           "gc_host_pack_weight", "gc_host_pack_edges", "gc_host_pad_latent", "gc_advance_state", "gc_rowmlp", "gc_seg_fixup", "gc_zero_rows", "gc_seg_fixup_bf16", "gc_zero_rows_bf16", "gc_add_rows", "gc_prep_grid_input", "gc_prep_grid_tail",
            "gc_run_program", "gc_time_program", "gc_abi_sizeof", "gc_last_error", "gc_build_info")
 
 
@@ -325,6 +325,9 @@ def lib():
     l.gc_host_pack_edges.argtypes = [ctypes.c_int, _fp, _fp, ctypes.c_int] + [_fp] * 5 + [
         ctypes.POINTER(ctypes.c_int), _fp, ctypes.POINTER(ctypes.c_int)]
     l.gc_host_pack_edges.restype = ctypes.c_int
+    l.gc_host_pad_latent.argtypes = [ctypes.POINTER(TensorDesc), ctypes.c_int, ctypes.c_int, _fp, ctypes.c_longlong,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    l.gc_host_pad_latent.restype = ctypes.c_int
     l.gc_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
     l.gc_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
     l.gc_plan_get_tuning.argtypes = [ctypes.c_void_p, ctypes.POINTER(Tuning)]

@@ -106,11 +106,15 @@ class GraphCast(predictor_base.Predictor):
     grid-node order, as an array or the path of a ``.npy`` file.  A host that has trimesh can
     supply the reference's exact choice (it only matters for the grid points lying exactly on a
     mesh edge: 254 at 0.25 deg); without it the restated rule of grid_mesh_connectivity.py runs."""
-    if model_config.hidden_layers != 1:
-      raise NotImplementedError("the MI355X build fuses exactly one hidden layer per MLP "
-                                "(hidden_layers=1, the value of every published GraphCast)")
-    if model_config.latent_size != 512:
-      raise NotImplementedError("the MI355X kernels are built for latent_size=512")
+    if model_config.hidden_layers < 1:
+      # (round 6: hidden_layers > 1 runs as one further launch of the same kernels per further hidden layer --
+      #  csrc/gcast_plan.inc: push_mlp; the fused single launch is the hidden_layers=1 of every published GraphCast)
+      raise NotImplementedError("hidden_layers must be >= 1: an MLP that is a single Linear (hidden_layers=0) is not built")
+    if model_config.latent_size <= 0 or model_config.latent_size > 512 or 512 % model_config.latent_size:
+      # (round 6: a latent size that divides 512 runs on the same 512-column kernels through padded parameters --
+      #  csrc/gcast_plan.inc: pad_latent; correct, at the 512-wide model's cost)
+      raise NotImplementedError("the MI355X kernels' tile is 512 columns wide: latent_size must divide 512 "
+                                f"(512; or 256, 128, 64, ... through padded parameters), got {model_config.latent_size}")
     self._model_config = model_config
     self._task_config = task_config
     self._device = device
@@ -278,11 +282,28 @@ class GraphCast(predictor_base.Predictor):
         mesh_node_feat=self._grid2mesh_graph_structure.nodes["mesh_nodes"].features,
         g2m=pick(g2m), mesh=pick(mesh), m2g=pick(m2g))
 
+  def _check_params_fit_the_config(self):
+    """The plan reads latent size and number of hidden layers off the parameter tree (include/gcast.h: gc_plan_create);
+    the reference builds its haiku modules from the ModelConfig and fails on a checkpoint of another shape
+    (``weathernext1_graph/graphcast.py:123-124,138-139``) -- so does this."""
+    stem = "grid2mesh_gnn/~_networks_builder/encoder_nodes_grid_nodes_mlp/~/linear_"
+    if stem + "0" not in self._params:
+      raise ValueError(f"missing parameters for module {stem + '0'!r}")
+    latent = int(np.shape(self._params[stem + "0"]["w"])[1])
+    layers = 0
+    while stem + str(layers + 1) in self._params:
+      layers += 1
+    cfg = self._model_config
+    if latent != cfg.latent_size or layers != cfg.hidden_layers:
+      raise ValueError(f"parameters are those of a model with latent_size={latent}, hidden_layers={layers}; the ModelConfig "
+                       f"says latent_size={cfg.latent_size}, hidden_layers={cfg.hidden_layers}")
+
   # ---------------------------------------------------------------- tensor boundary
   def _get_engine(self, c_in):
     if self._engine is None:
       if self._params is None:
         raise ValueError("GraphCast has no parameters: pass params= or call load_params()")
+      self._check_params_fit_the_config()
       from graphcast_amd import engine      # needs the HIP library; fails loudly without it
       self._engine = engine.StepEngine(
           self.graph_arrays(), self._params, num_steps=self._model_config.gnn_msg_steps,

@@ -430,8 +430,23 @@ typedef struct gc_tensor_desc {
   int rows, cols;
 } gc_tensor_desc;
 
+/* Sizes other than the published ones (round 6).  The kernels' tile is GC_LATENT = 512 columns and fuses ONE hidden
+ * layer; gc_plan_create reads both sizes off the parameter tree (ModelConfig.latent_size / hidden_layers,
+ * weathernext1_graph/graphcast.py:123-124; deep_typed_graph_net.py:205-209) --
+ *   latent size L < 512, L dividing 512: the parameters are re-shaped once (zero-padded latent axes; the output
+ *     columns of every Linear that feeds a LayerNorm REPLICATED 512 / L times, so that the statistics over 512 columns
+ *     are those over the L real ones) and the same launches run: correct, at the 512-wide model's cost.  Other L:
+ *     GC_EINVAL;
+ *   n > 1 hidden layers ("<stem>_mlp/~/linear_0" .. "linear_n"): one further launch of the same kernels per further
+ *     hidden layer, pre-activation rows handed on through the workspace; the output MLP then runs as launches of
+ *     its own instead of as chained stages.  n = 0 (a single Linear): GC_EINVAL. */
 int gc_plan_create(const gc_model_desc* model, const gc_tensor_desc* tensors, int n_tensors,
                    void* stream, gc_plan** out);
+/* The re-shaping for L < 512 on its own (host only, no device): tensor `index` of the tree as gc_plan_create would
+ * see it -- *rows x *cols, copied to h_out when that is not NULL (capacity in floats).  Exported so that a binding can
+ * check the rule (tests/test_native_abi.py: the oracle gives the same step on the re-shaped tree). */
+int gc_host_pad_latent(const gc_tensor_desc* tensors, int n_tensors, int index, float* h_out, long long capacity,
+                       int* rows, int* cols);
 size_t gc_plan_workspace_bytes(const gc_plan* plan, int batch);
 int gc_step_forward(const gc_plan* plan, const float* x, float* y, int batch, void* workspace,
                     size_t workspace_bytes, void* stream);

@@ -1,0 +1,109 @@
+"""ModelConfig.latent_size / hidden_layers other than the published 512 / 1
+(``weathernext1_graph/graphcast.py:123-124,138-139``; ``utils/legacy/deep_typed_graph_net.py:205-209``:
+``hk.nets.MLP([mlp_hidden_size] * mlp_num_hidden_layers + [latent_size])``) against the oracle, which restates the
+MLP for any number of Linear layers and any width (``oracle/gnn.py: _Net.apply``).
+
+The kernels' tile stays 512 columns wide: a narrower latent runs through padded parameters (csrc/gcast_plan.inc:
+pad_latent -- zero-padded latent axes, the LayerNorm-fed output columns replicated so that the statistics over 512
+columns are the statistics over the L real ones), further hidden layers as further launches of the same kernels
+(csrc/gcast_plan.inc: push_mlp).  Tolerances: those of tests/test_step_gpu.py (fp32-grade tiers) and of
+tests/test_bf16_tier_gpu.py (the Bfloat16Cast tier against its op-by-op restatement).
+"""
+import numpy as np
+import pytest
+import torch
+
+from graphcast_amd import graphcast as gc
+from oracle import gnn as ognn
+from oracle import graphcast as ogc
+from oracle import params as oparams
+
+pytestmark = pytest.mark.gpu
+
+REL_RMSE_TOL = 2e-5       # tests/test_step_gpu.py
+
+
+def rel_rmse(got, want):
+  return float(np.linalg.norm(np.asarray(got, np.float64) - want) / np.linalg.norm(want))
+
+
+def general_params(c_in, c_out, latent, steps, hidden_layers, seed=3):
+  """oracle.params.init_params for `hidden_layers` hidden layers of `latent` units (non-trivial biases / LayerNorms)."""
+  rng = np.random.default_rng(seed)
+  params = {}
+  for stem, sizes, ln in oparams.module_specs(c_in, c_out, latent, steps):
+    sizes = [sizes[0]] + [latent] * hidden_layers + [sizes[-1]]
+    for k in range(len(sizes) - 1):
+      fan_in, fan_out = sizes[k], sizes[k + 1]
+      w = np.clip(rng.standard_normal((fan_in, fan_out)), -2, 2) / np.sqrt(fan_in)
+      params[f"{stem}_mlp/~/linear_{k}"] = {"w": w.astype(np.float32),
+                                            "b": (0.1 * rng.standard_normal(fan_out)).astype(np.float32)}
+    if ln:
+      params[f"{stem}_layer_norm"] = {"scale": (1 + 0.1 * rng.standard_normal(sizes[-1])).astype(np.float32),
+                                      "offset": (0.1 * rng.standard_normal(sizes[-1])).astype(np.float32)}
+  return params
+
+
+def build(latent, hidden_layers, precision, c_in=183):
+  if not torch.cuda.is_available():
+    pytest.fail("GPU test selected but no GPU is visible")
+  res, mesh_size, steps = 4.0, 3, 3
+  lat = np.arange(-90, 90 + res / 2, res)
+  lon = np.arange(0, 360, res)
+  cfg = gc.ModelConfig(resolution=res, mesh_size=mesh_size, latent_size=latent, gnn_msg_steps=steps,
+                       hidden_layers=hidden_layers, radius_query_fraction_edge_length=0.6)
+  c_out = gc.num_output_channels(gc.TASK_13)
+  params = general_params(c_in, c_out, latent, steps, hidden_layers)
+  model = gc.GraphCast(cfg, gc.TASK_13, params=params, precision=precision).init_from_coordinates(lat, lon)
+  return model, ogc.build_graphs(lat, lon, mesh_size), params, steps, c_in
+
+
+CASES = [(256, 1), (64, 1), (128, 1), (512, 2), (512, 3), (256, 2)]
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("latent,hidden_layers", CASES)
+def test_step_of_a_general_size_matches_the_oracle(latent, hidden_layers, precision):
+  model, graphs, params, steps, c_in = build(latent, hidden_layers, precision)
+  for batch in (1, 2):
+    x = np.random.default_rng(batch).standard_normal((graphs["n_grid"], batch, c_in)).astype(np.float32)
+    want = ogc.forward(params, graphs, x, steps=steps, dtype=np.float64)
+    y = model.forward_grid_node_features(torch.from_numpy(x).to("cuda:0"))
+    y2 = model.forward_grid_node_features(torch.from_numpy(x).to("cuda:0"))
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    err = rel_rmse(got, want)
+    print(f"GENERAL_SIZE latent={latent} hidden_layers={hidden_layers} {precision} batch={batch}: rel-RMSE vs the float64 "
+          f"oracle {err:.3e}")
+    assert np.isfinite(got).all() and got.shape == want.shape
+    assert err <= REL_RMSE_TOL
+    assert torch.equal(y, y2)                     # deterministic, as every other launch sequence of the library
+
+
+@pytest.mark.parametrize("latent,hidden_layers", [(256, 1), (64, 1), (512, 2), (128, 3)])
+def test_bf16_tier_of_a_general_size(latent, hidden_layers):
+  """The Bfloat16Cast tier: against the fp64 truth the step must be as good as the op-by-op bf16 restatement of the
+  reference is (tests/test_bf16_tier_gpu.py's criterion)."""
+  model, graphs, params, steps, c_in = build(latent, hidden_layers, "bf16")
+  x = np.random.default_rng(5).standard_normal((graphs["n_grid"], 1, c_in)).astype(np.float32)
+  got = model.forward_grid_node_features(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+  truth = ogc.forward(params, graphs, x, steps=steps, dtype=np.float64)
+  with ognn.activations("bf16"):
+    ref_bf16 = ogc.forward(params, graphs, x, steps=steps, dtype=np.float32, f32_aggregation=True)
+  e_hip, e_ref = rel_rmse(got, truth), rel_rmse(ref_bf16, truth)
+  print(f"GENERAL_SIZE_BF16 latent={latent} hidden_layers={hidden_layers}: HIP vs truth {e_hip:.3e}, restatement vs truth "
+        f"{e_ref:.3e}")
+  assert np.isfinite(got).all()
+  assert e_hip <= 1.25 * e_ref
+
+
+def test_sizes_the_tile_cannot_hold_are_rejected_loudly():
+  for latent in (384, 1024, 100):
+    cfg = gc.ModelConfig(resolution=4.0, mesh_size=3, latent_size=latent, gnn_msg_steps=1, hidden_layers=1,
+                         radius_query_fraction_edge_length=0.6)
+    with pytest.raises(NotImplementedError, match="divide 512"):
+      gc.GraphCast(cfg, gc.TASK_13, params={})
+  cfg = gc.ModelConfig(resolution=4.0, mesh_size=3, latent_size=512, gnn_msg_steps=1, hidden_layers=0,
+                       radius_query_fraction_edge_length=0.6)
+  with pytest.raises(NotImplementedError, match="hidden_layers"):
+    gc.GraphCast(cfg, gc.TASK_13, params={})

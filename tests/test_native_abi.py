@@ -213,3 +213,59 @@ def test_micro_benchmarks_cross_compile_for_gfx950(name, tmp_path):
   r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-c", src, "-o", str(tmp_path / (name + ".o"))],
                      capture_output=True, text=True, timeout=300)
   assert r.returncode == 0, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("latent,hidden_layers", [(64, 1), (128, 2), (256, 1)])
+def test_padded_parameters_of_a_narrow_latent_give_the_same_step(built, latent, hidden_layers):
+  """gc_plan_create runs a model whose latent size L divides 512 on the 512-column kernels by re-shaping its PARAMETERS
+  (csrc/gcast_plan.inc: pad_latent; zero-padded latent axes, LayerNorm-fed output columns replicated 512 / L times).
+  The rule itself, checked without a GPU: the oracle (oracle/graphcast.py, ANY width) gives the same step on the tree
+  gc_host_pad_latent hands back -- a latent-512 model -- as on the original one (weathernext1_graph/graphcast.py:123,
+  deep_typed_graph_net.py:205-247)."""
+  import numpy as np
+  from graphcast_amd.engine import tensor_descs
+  from oracle import graphcast as ogc
+  from oracle import params as oparams
+  lib = built.lib()
+  c_in, c_out, steps = 11, 5, 2
+  rng = np.random.default_rng(latent + hidden_layers)
+  params = {}
+  for stem, sizes, ln in oparams.module_specs(c_in, c_out, latent, steps):
+    sizes = [sizes[0]] + [latent] * hidden_layers + [sizes[-1]]
+    for k in range(len(sizes) - 1):
+      params[f"{stem}_mlp/~/linear_{k}"] = {
+          "w": (rng.standard_normal((sizes[k], sizes[k + 1])) / np.sqrt(sizes[k])).astype(np.float32),
+          "b": (0.1 * rng.standard_normal(sizes[k + 1])).astype(np.float32)}
+    if ln:
+      params[f"{stem}_layer_norm"] = {"scale": (1 + 0.1 * rng.standard_normal(sizes[-1])).astype(np.float32),
+                                      "offset": (0.1 * rng.standard_normal(sizes[-1])).astype(np.float32)}
+  descs, keep = tensor_descs(params)
+  padded = {}
+  for i, t in enumerate(descs):
+    rows, cols = ctypes.c_int(), ctypes.c_int()
+    assert lib.gc_host_pad_latent(descs, len(descs), i, None, 0, ctypes.byref(rows), ctypes.byref(cols)) == 0, lib.gc_last_error()
+    out = np.empty((rows.value, cols.value), np.float32)
+    assert lib.gc_host_pad_latent(descs, len(descs), i, out.ctypes.data, out.size, None, None) == 0, lib.gc_last_error()
+    module, leaf = t.name.decode().rsplit("/", 1)
+    padded.setdefault(module, {})[leaf] = out if leaf == "w" else out[0]
+  D = nat.LATENT
+  for module, leaves in padded.items():           # every latent axis is 512 wide now; raw-feature rows / c_out columns stay
+    for leaf, a in leaves.items():
+      decoder_out = "decoder_" in module and module.endswith(f"linear_{hidden_layers}")
+      assert a.shape[-1] == (c_out if decoder_out else D), (module, leaf, a.shape)
+  res, mesh_size = 12.0, 2
+  lat, lon = np.arange(-90, 90 + res / 2, res), np.arange(0, 360, res)
+  graphs = ogc.build_graphs(lat, lon, mesh_size)
+  x = rng.standard_normal((graphs["n_grid"], 2, c_in)).astype(np.float32)      # (module_specs adds the 3 structural features)
+  want = ogc.forward(params, graphs, x, steps=steps, dtype=np.float64)
+  got = ogc.forward(padded, graphs, x, steps=steps, dtype=np.float64)
+  err = np.linalg.norm(got - want) / np.linalg.norm(want)
+  assert err < 1e-12, err
+  # and sizes the tile cannot hold are refused by name
+  bad = {k: dict(v) for k, v in params.items()}
+  stem = "grid2mesh_gnn/~_networks_builder/encoder_nodes_grid_nodes_mlp/~/linear_0"
+  bad[stem]["w"] = np.zeros((bad[stem]["w"].shape[0], 384), np.float32)
+  d2, keep2 = tensor_descs(bad)
+  assert lib.gc_host_pad_latent(d2, len(d2), 0, None, 0, None, None) == nat.EINVAL
+  assert b"divide 512" in lib.gc_last_error()
+  del keep, keep2
