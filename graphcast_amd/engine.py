@@ -210,7 +210,8 @@ class StepEngine(launch.LaunchBase):
           if (self.wide_min_rows is not None and m.n_rows >= self.wide_min_rows and m.mode == nat.MODE_MLP_LN
               and m.k0 + m.k1 > 0):
             m.flags |= nat.WG_WIDE
-          elif self.helpers_min_rows and m.n_rows >= self.helpers_min_rows:
+          elif self.helpers_min_rows and m.n_rows >= self.helpers_min_rows and m.k0 + m.k1 > 0:
+            # (k0 + k1 > 0: the addend-only launches of a hidden_layers > 1 plan stay in the four-wave form, as in the plan's own rule)
             m.flags |= nat.WG_HELPERS
     if self.wide_edges:
       for k in range(n.value):

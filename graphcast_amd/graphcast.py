@@ -110,11 +110,11 @@ class GraphCast(predictor_base.Predictor):
       # (round 6: hidden_layers > 1 runs as one further launch of the same kernels per further hidden layer --
       #  csrc/gcast_plan.inc: push_mlp; the fused single launch is the hidden_layers=1 of every published GraphCast)
       raise NotImplementedError("hidden_layers must be >= 1: an MLP that is a single Linear (hidden_layers=0) is not built")
-    if model_config.latent_size <= 0 or model_config.latent_size > 512 or 512 % model_config.latent_size:
-      # (round 6: a latent size that divides 512 runs on the same 512-column kernels through padded parameters --
+    if model_config.latent_size <= 0 or model_config.latent_size > 512:
+      # (round 6: a latent size below 512 runs on the same 512-column kernels through padded parameters --
       #  csrc/gcast_plan.inc: pad_latent; correct, at the 512-wide model's cost)
-      raise NotImplementedError("the MI355X kernels' tile is 512 columns wide: latent_size must divide 512 "
-                                f"(512; or 256, 128, 64, ... through padded parameters), got {model_config.latent_size}")
+      raise NotImplementedError("the MI355X kernels' tile is 512 columns wide: latent_size must be in 1 .. 512 "
+                                f"(narrower latents run through padded parameters), got {model_config.latent_size}")
     self._model_config = model_config
     self._task_config = task_config
     self._device = device

@@ -433,10 +433,11 @@ typedef struct gc_tensor_desc {
 /* Sizes other than the published ones (round 6).  The kernels' tile is GC_LATENT = 512 columns and fuses ONE hidden
  * layer; gc_plan_create reads both sizes off the parameter tree (ModelConfig.latent_size / hidden_layers,
  * weathernext1_graph/graphcast.py:123-124; deep_typed_graph_net.py:205-209) --
- *   latent size L < 512, L dividing 512: the parameters are re-shaped once (zero-padded latent axes; the output
- *     columns of every Linear that feeds a LayerNorm REPLICATED 512 / L times, so that the statistics over 512 columns
- *     are those over the L real ones) and the same launches run: correct, at the 512-wide model's cost.  Other L:
- *     GC_EINVAL;
+ *   latent size L < 512: the parameters are re-shaped once (zero-padded latent axes; the output columns of every Linear
+ *     that feeds a LayerNorm REPLICATED floor(512 / L) times -- and, where L does not divide 512, the remaining columns
+ *     filled with the MEAN column and the Linear / the LayerNorm scale rescaled by sqrt(512 / (R L)) and its inverse --
+ *     so that the statistics the kernels form over 512 columns are exactly those over the L real ones) and the same
+ *     launches run: correct, at the 512-wide model's cost.  L > 512: GC_EINVAL;
  *   n > 1 hidden layers ("<stem>_mlp/~/linear_0" .. "linear_n"): one further launch of the same kernels per further
  *     hidden layer, pre-activation rows handed on through the workspace; the output MLP then runs as launches of
  *     its own instead of as chained stages.  n = 0 (a single Linear): GC_EINVAL. */

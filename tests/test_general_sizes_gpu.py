@@ -4,8 +4,9 @@
 MLP for any number of Linear layers and any width (``oracle/gnn.py: _Net.apply``).
 
 The kernels' tile stays 512 columns wide: a narrower latent runs through padded parameters (csrc/gcast_plan.inc:
-pad_latent -- zero-padded latent axes, the LayerNorm-fed output columns replicated so that the statistics over 512
-columns are the statistics over the L real ones), further hidden layers as further launches of the same kernels
+pad_latent -- zero-padded latent axes, the LayerNorm-fed output columns replicated (plus, where L does not divide 512, the
+mean column and a rescaling LayerNorm's scale invariance undoes) so that the statistics over 512 columns are the
+statistics over the L real ones), further hidden layers as further launches of the same kernels
 (csrc/gcast_plan.inc: push_mlp).  Tolerances: those of tests/test_step_gpu.py (fp32-grade tiers) and of
 tests/test_bf16_tier_gpu.py (the Bfloat16Cast tier against its op-by-op restatement).
 """
@@ -58,7 +59,7 @@ def build(latent, hidden_layers, precision, c_in=183):
   return model, ogc.build_graphs(lat, lon, mesh_size), params, steps, c_in
 
 
-CASES = [(256, 1), (64, 1), (128, 1), (512, 2), (512, 3), (256, 2)]
+CASES = [(256, 1), (64, 1), (128, 1), (512, 2), (512, 3), (256, 2), (384, 1), (100, 2), (320, 1)]
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
@@ -80,7 +81,7 @@ def test_step_of_a_general_size_matches_the_oracle(latent, hidden_layers, precis
     assert torch.equal(y, y2)                     # deterministic, as every other launch sequence of the library
 
 
-@pytest.mark.parametrize("latent,hidden_layers", [(256, 1), (64, 1), (512, 2), (128, 3)])
+@pytest.mark.parametrize("latent,hidden_layers", [(256, 1), (64, 1), (512, 2), (128, 3), (384, 1), (200, 2)])
 def test_bf16_tier_of_a_general_size(latent, hidden_layers):
   """The Bfloat16Cast tier: against the fp64 truth the step must be as good as the op-by-op bf16 restatement of the
   reference is (tests/test_bf16_tier_gpu.py's criterion)."""
@@ -98,10 +99,10 @@ def test_bf16_tier_of_a_general_size(latent, hidden_layers):
 
 
 def test_sizes_the_tile_cannot_hold_are_rejected_loudly():
-  for latent in (384, 1024, 100):
+  for latent in (1024, 513, 0):
     cfg = gc.ModelConfig(resolution=4.0, mesh_size=3, latent_size=latent, gnn_msg_steps=1, hidden_layers=1,
                          radius_query_fraction_edge_length=0.6)
-    with pytest.raises(NotImplementedError, match="divide 512"):
+    with pytest.raises(NotImplementedError, match="1 .. 512"):
       gc.GraphCast(cfg, gc.TASK_13, params={})
   cfg = gc.ModelConfig(resolution=4.0, mesh_size=3, latent_size=512, gnn_msg_steps=1, hidden_layers=0,
                        radius_query_fraction_edge_length=0.6)

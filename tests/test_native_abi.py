@@ -215,10 +215,11 @@ def test_micro_benchmarks_cross_compile_for_gfx950(name, tmp_path):
   assert r.returncode == 0, r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("latent,hidden_layers", [(64, 1), (128, 2), (256, 1)])
+@pytest.mark.parametrize("latent,hidden_layers", [(64, 1), (128, 2), (256, 1), (384, 1), (100, 2), (7, 1)])
 def test_padded_parameters_of_a_narrow_latent_give_the_same_step(built, latent, hidden_layers):
   """gc_plan_create runs a model whose latent size L divides 512 on the 512-column kernels by re-shaping its PARAMETERS
-  (csrc/gcast_plan.inc: pad_latent; zero-padded latent axes, LayerNorm-fed output columns replicated 512 / L times).
+  (csrc/gcast_plan.inc: pad_latent; zero-padded latent axes, LayerNorm-fed output columns replicated floor(512 / L) times,
+  the mean column + a rescaling where L does not divide 512).
   The rule itself, checked without a GPU: the oracle (oracle/graphcast.py, ANY width) gives the same step on the tree
   gc_host_pad_latent hands back -- a latent-512 model -- as on the original one (weathernext1_graph/graphcast.py:123,
   deep_typed_graph_net.py:205-247)."""
@@ -260,12 +261,14 @@ def test_padded_parameters_of_a_narrow_latent_give_the_same_step(built, latent, 
   want = ogc.forward(params, graphs, x, steps=steps, dtype=np.float64)
   got = ogc.forward(padded, graphs, x, steps=steps, dtype=np.float64)
   err = np.linalg.norm(got - want) / np.linalg.norm(want)
-  assert err < 1e-12, err
+  # L dividing 512: pure copies and zeros -- the fp64 oracle cannot tell the trees apart.  Otherwise the Linear's columns
+  # and the LayerNorm scale carry sqrt(512 / (R L)) and its inverse, each rounded to float32 once (6e-8 relative).
+  assert err < (1e-12 if D % latent == 0 else 1e-6), err
   # and sizes the tile cannot hold are refused by name
   bad = {k: dict(v) for k, v in params.items()}
   stem = "grid2mesh_gnn/~_networks_builder/encoder_nodes_grid_nodes_mlp/~/linear_0"
-  bad[stem]["w"] = np.zeros((bad[stem]["w"].shape[0], 384), np.float32)
+  bad[stem]["w"] = np.zeros((bad[stem]["w"].shape[0], 640), np.float32)
   d2, keep2 = tensor_descs(bad)
   assert lib.gc_host_pad_latent(d2, len(d2), 0, None, 0, None, None) == nat.EINVAL
-  assert b"divide 512" in lib.gc_last_error()
+  assert b"1 .. 512" in lib.gc_last_error()
   del keep, keep2
