@@ -271,7 +271,9 @@ class StepEngine(launch.LaunchBase):
     processor step, 1 decoder; every rank of a partitioned step has the same segment structure."""
     ops, y = self.bind(x, y)
     cuts = [(k, _EDGE_TAGS[ops[k].tag]) for k in range(len(ops))
-            if ops[k].kind == nat.OP_ROWMLP and ops[k].tag in _EDGE_TAGS]
+            if ops[k].kind == nat.OP_ROWMLP and ops[k].tag in _EDGE_TAGS and ops[k].mlp.g0]
+    # (`mlp.g0`: the launch that GATHERS -- every edge update of a one-hidden-layer plan, the first of the n launches
+    #  an edge MLP with n hidden layers is, csrc/gcast_plan.inc: push_mlp)
     with torch.cuda.device(self.dev):
       self._clear_tile_queue()
     segs, lo = [], 0

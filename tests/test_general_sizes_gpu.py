@@ -108,3 +108,25 @@ def test_sizes_the_tile_cannot_hold_are_rejected_loudly():
                        radius_query_fraction_edge_length=0.6)
   with pytest.raises(NotImplementedError, match="hidden_layers"):
     gc.GraphCast(cfg, gc.TASK_13, params={})
+
+
+@pytest.mark.parametrize("latent,hidden_layers,precision", [(256, 2, "f16x3"), (384, 1, "f16x3"), (128, 2, "bf16")])
+def test_partitioned_step_of_a_general_size(latent, hidden_layers, precision):
+  """The spatially partitioned step (tests/test_partition_gpu.py) on such a model: every rank's plan re-shapes the
+  same parameters, the halo exchanges sit in front of the launches that GATHER (the first of an edge MLP's n launches:
+  engine.segments), so their number per step is what it is for the published architecture."""
+  from graphcast_amd import partition
+  model, graphs, params, steps, c_in = build(latent, hidden_layers, precision)
+  x = torch.from_numpy(np.random.default_rng(4).standard_normal((graphs["n_grid"], 1, c_in)).astype(np.float32)).to("cuda:0")
+  y_full = model.forward_grid_node_features(x).clone()
+  step = partition.EmulatedPartitionedStep(
+      model.graph_arrays(), params, model._grid_nodes_lon, model._mesh_nodes_lon, 4, num_steps=steps, c_in=c_in,
+      c_out=gc.num_output_channels(gc.TASK_13), precision=precision, grid_lat=model._grid_nodes_lat,
+      mesh_lat=model._mesh_nodes_lat)
+  y = step(x)
+  torch.cuda.synchronize()
+  assert step.exchanges_per_call == 2 + steps
+  rel = float(torch.linalg.vector_norm((y - y_full).double()) / torch.linalg.vector_norm(y_full.double()))
+  print(f"GENERAL_SIZE_PARTITION latent={latent} hidden_layers={hidden_layers} {precision}: 4 parts vs unpartitioned {rel:.2e}")
+  assert torch.isfinite(y).all()
+  assert rel < (2e-2 if precision == "bf16" else 2e-6)
