@@ -1468,6 +1468,7 @@ const char* gc_tuning_string(const gc_tuning* tp) {
 const char* gc_build_info(void) {
   return "gfx950;tile=64x512;mfma=f32_16x16x4|3xf16_16x16x32|bf16_16x16x32;tiers=bf16(Bfloat16Cast);"
          "layouts=chunked(f32)|half(f16x3: 2wg/cu,persistent,chain)|half+helpers(8 waves,1wg/cu)|half+wide(8 multiplying waves,128 rows/ring,10/16 parked n-blocks in LDS,seg+onepass);ring=4x16k"
+         ";plan=latent<=512(padded parameters),hidden_layers>=1(one launch per further layer)"
          ";helpers_default=" GC_STR(GC_HELPERS_DEFAULT) ";wide_edges_default=" GC_STR(GC_WIDE_EDGES_DEFAULT)
 #ifdef GC_SRC_HASH
          ";src=" GC_SRC_HASH

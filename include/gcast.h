@@ -15,10 +15,13 @@
  *     gc_last_error() (thread-local);
  *   - fp32 tensors everywhere; the GEMMs run in one of two arithmetic modes
  *     (`gc_rowmlp_desc.prec`, below) that both deliver fp32-grade results;
- *     latent size is fixed at 512 (GraphCast's
- *     `latent_size`, weathernext1_graph/graphcast.py:123) and MLPs have exactly
- *     one hidden layer (`hidden_layers`, :124) -- other values are rejected
- *     loudly by the host code.
+ *     a launch's tile is 512 columns wide (GraphCast's `latent_size`,
+ *     weathernext1_graph/graphcast.py:123) and fuses exactly one hidden layer
+ *     (`hidden_layers`, :124): what every published GraphCast has.  The PLAN
+ *     API runs narrower latents and deeper MLPs on these launches (padded
+ *     parameters, one further launch per further hidden layer: see
+ *     gc_plan_create); a latent size above 512 or a single-Linear MLP is
+ *     rejected loudly.
  *
  * Packed weight layout ("k4-interleaved"): a haiku `w` of shape [K, N]
  * (x @ w, utils/legacy/deep_typed_graph_net.py:206-208) is stored as
