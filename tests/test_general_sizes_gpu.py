@@ -130,3 +130,21 @@ def test_partitioned_step_of_a_general_size(latent, hidden_layers, precision):
   print(f"GENERAL_SIZE_PARTITION latent={latent} hidden_layers={hidden_layers} {precision}: 4 parts vs unpartitioned {rel:.2e}")
   assert torch.isfinite(y).all()
   assert rel < (2e-2 if precision == "bf16" else 2e-6)
+
+
+def test_the_c_hosts_two_calls_on_a_general_size():
+  """gc_plan_create + gc_step_forward (plan.NativePlan: what a C / C++ host drives, include/gcast.h) on a (384, 2)
+  model: the same bits as the Python engine's program of the same plan, and the oracle's step."""
+  from graphcast_amd import plan
+  model, graphs, params, steps, c_in = build(384, 2, "f16x3")
+  x = np.random.default_rng(8).standard_normal((graphs["n_grid"], 2, c_in)).astype(np.float32)
+  xd = torch.from_numpy(x).to("cuda:0")
+  y_engine = model.forward_grid_node_features(xd).clone()
+  native = plan.NativePlan(model.graph_arrays(), params, num_steps=steps, c_in=c_in,
+                           c_out=gc.num_output_channels(gc.TASK_13), precision="f16x3")
+  y = native(xd)
+  native.check_range()
+  assert torch.equal(y, y_engine)
+  want = ogc.forward(params, graphs, x, steps=steps, dtype=np.float64)
+  assert rel_rmse(y.cpu().numpy(), want) <= REL_RMSE_TOL
+  native.close()

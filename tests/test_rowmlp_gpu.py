@@ -446,6 +446,35 @@ def test_prep_grid_input(dev):
   assert (got[:, c_in + 3:] == 0).all()
 
 
+@pytest.mark.parametrize("n,batch,b,c_in,c0,n_struct,kt,offset", [
+    (1000, 3, 1, 471, 448, 3, 32, 0),        # the 0.25 deg shape: [x[:, b, 448:] | struct | 0]
+    (1037, 2, 0, 183, 160, 3, 32, 0),        # 1 deg; rows not a multiple of the block's 32
+    (513, 1, 0, 20, 0, 3, 32, 0),            # fewer than 32 input channels: the tail is the whole input
+    (257, 2, 1, 96, 64, 0, 32, 0),           # no structural features
+    (300, 2, 1, 100, 64, 3, 64, 0),          # a 64-column tail
+    (300, 2, 1, 100, 64, 3, 64, 1),          # xt not 16-byte aligned: the one-wave-per-row kernel
+])
+def test_prep_grid_tail(dev, n, batch, b, c_in, c0, n_struct, kt, offset):
+  """gc_prep_grid_tail (round 6: one float4 of the output per thread where xt is 16-byte aligned) against the
+  concat it replaces, graphcast.py:561-568, for the columns c0 .. c0 + kt - 1."""
+  rng = np.random.default_rng(n + kt)
+  x = rng.standard_normal((n, batch, c_in)).astype(np.float32)
+  st = rng.standard_normal((n, max(n_struct, 1))).astype(np.float32)
+  tx, ts = up(x, dev), up(st[:, :n_struct] if n_struct else st, dev)
+  buf = torch.full((n * kt + 4,), float("nan"), device=dev)
+  xt = buf[offset:offset + n * kt].view(n, kt)
+  lib = nat.lib()
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  nat.check(lib.gc_prep_grid_tail(n, batch, b, c_in, c0, tx.data_ptr(), n_struct, ts.data_ptr() if n_struct else None,
+                                  kt, xt.data_ptr(), stream), "gc_prep_grid_tail")
+  torch.cuda.synchronize()
+  want = np.zeros((n, kt), np.float32)
+  want[:, :c_in - c0] = x[:, b, c0:]
+  want[:, c_in - c0:c_in - c0 + n_struct] = st[:, :n_struct]
+  np.testing.assert_array_equal(xt.cpu().numpy(), want)
+  assert torch.isnan(buf[:offset]).all() and torch.isnan(buf[offset + n * kt:]).all()      # nothing written outside
+
+
 # ---- GC_LAYOUT_HALF only: chained stages and in-place (unaligned) layer-1 rows ------------------
 def _half_only():
   if not _HALF:
