@@ -636,7 +636,7 @@ def test_arithmetic_aligns_on_level_labels_like_the_reference_normalisation():
     rollout_device._stat(mean, "temperature", 501, 0.0)
 
 
-@pytest.mark.parametrize("tag", ["r03_final2", "r04_final", "r05_final", "r06_final2", "r06_final3", "r06_final4", "r06_final5"])
+@pytest.mark.parametrize("tag", ["r03_final2", "r04_final", "r05_final", "r06_final2", "r06_final3", "r06_final4", "r06_final5", "r06_final7"])
 def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows(tag):
   """profiles/<tag>_sq_by_stage.json (MFMA pipe busy per stage) is what
   scripts/sq_by_stage.py computes from the committed rocprofv3 counter rows of the same session (r04: the launches
@@ -662,10 +662,10 @@ def test_committed_sq_summary_is_reproducible_from_the_committed_counter_rows(ta
   assert got["proc_edge"]["lds_bank_conflict"] == 0.0
 
 
-@pytest.mark.parametrize("tag", ["r03_final2", "r04_final", "r05_final", "r06_final", "r06_final2", "r06_final3", "r06_final4", "r06_final5"])
+@pytest.mark.parametrize("tag", ["r03_final2", "r04_final", "r05_final", "r06_final", "r06_final2", "r06_final3", "r06_final4", "r06_final5", "r06_final7"])
 def test_committed_traffic_summary_is_reproducible_from_the_committed_counter_rows(tag):
   """profiles/<tag>_pmc_by_stage.json (L2 <-> fabric bytes per stage) from the committed FETCH_SIZE / WRITE_SIZE rows;
-  the LATEST (r06_final5) is also profiles/current_pmc_by_stage.json, what bench.py attaches as roofline.traffic when the loaded
+  the LATEST (r06_final7) is also profiles/current_pmc_by_stage.json, what bench.py attaches as roofline.traffic when the loaded
   library was built from the sources the passes ran on."""
   import json
   import os
@@ -688,7 +688,7 @@ def test_committed_traffic_summary_is_reproducible_from_the_committed_counter_ro
     with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
       table = json.load(f)
     assert table["f16x3h:proc_edge"]["bytes_per_launch"] == want["proc_edge"]["traffic_bytes_per_launch"]
-  elif tag == "r06_final5":
+  elif tag == "r06_final7":
     with open(os.path.join(root, "profiles", "current_pmc_by_stage.json")) as f:
       cur = json.load(f)
     assert cur["proc_edge"] == want["proc_edge"] and len(cur["_stamp"]["src"]) == 16
