@@ -235,5 +235,26 @@ PY
     gate "$OUT/pytest.log" "landing guards"
     timeout 1200 python scripts/repeat_stress.py --reps 60 --out "$OUT/repeat_stress.json" 2>&1 | grep -v amdgpu.ids | cut -c1-300 | tail -6; echo "stress rc=${PIPESTATUS[0]}"
     ;;
+  s24|s26)
+    # Round-6 sessions 24 / 26: ModelConfig.latent_size / hidden_layers other than 512 / 1 (csrc/gcast_plan.inc: pad_latent,
+    # push_mlp) against the fp64 oracle in three precisions (s24: latent sizes dividing 512; s26: + 384, 320, 100, 200),
+    # with the published model's step / plan tests beside them.
+    timeout 1200 python -m pytest tests/test_general_sizes_gpu.py -q -m gpu -s 2>&1 | grep -v amdgpu.ids | grep -E "GENERAL|passed|failed" > "$OUT/general.log"; tail -40 "$OUT/general.log"
+    timeout 900 python -m pytest tests/test_step_gpu.py tests/test_plan_gpu.py -q -m gpu 2>&1 | tail -3
+    ;;
+  s25|s28)
+    # Round-6 sessions 25 / 28: the same sizes AT the headline graph -- f16x3 against the exact-fp32 kernel family, the bf16
+    # tier against f16x3, bitwise repeatability, ms per step (s28: with the layer-1 K of narrow latents trimmed,
+    # gc_plan.k_lat, and the rewritten input-tail kernel; + the prep tests and one bench line for the stage times).
+    timeout 1400 python scripts/general_sizes_fullsize.py --cases "${CASES:-256x1,384x1,128x1,512x2,64x2,128x3}" --out "$OUT/general_sizes_fullsize.json" 2>&1 | grep -v amdgpu.ids | tail -8
+    timeout 300 python -m pytest tests/test_rowmlp_gpu.py -q -m gpu -k prep 2>&1 | tail -2
+    timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cross-check --rollout-steps 0 2>/dev/null | cut -c1-400
+    ;;
+  s27)
+    # Round-6 session 27: the paths around the step on the library of final5 -- repeatability stress, emulated 8-way rank, 1 deg.
+    timeout 1200 python scripts/repeat_stress.py --reps 40 --out "$OUT/repeat_stress.json" 2>&1 | grep -v amdgpu.ids | cut -c1-250 | tail -6
+    timeout 900 python scripts/partition_emulated_bench.py --parts 8 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-600
+    timeout 600 python bench.py --config 1deg_13L_M5 --no-cpu-baseline --rollout-steps 0 2>/dev/null | cut -c1-300
+    ;;
   *) echo "unknown session $NAME"; exit 2;;
 esac
