@@ -900,3 +900,26 @@ def test_fused_rollout_recognises_the_demo_stack_and_nothing_else():
   other = normalization.InputsAndResiduals(gcm.GraphCast(cfg, gcm.TASK_13, device="cuda:0"), std, mean, dstd)
   assert rollout._fused_stack(rollout.fuse(lambda rng, **kw: (stack if rng else other)(**kw))) is None  # two stacks: ambiguous
   assert rollout._fused_stack(print) is None and rollout._fused_stack(None) is None and rollout._fused_stack(rollout.fuse(print)) is None
+
+
+def test_model_sizes_are_gated_and_checked_against_the_parameters():
+  """ModelConfig.latent_size / hidden_layers (weathernext1_graph/graphcast.py:123-124): any depth >= 1 and any width up
+  to the kernels' 512-column tile are accepted; what the tile cannot hold is refused by name, and a
+  parameter tree of another shape than the config says is a ValueError -- haiku would fail on it too."""
+  import numpy as np
+  from graphcast_amd import graphcast as gcm
+  from graphcast_amd import params as gparams
+  mk = lambda latent, hidden: gcm.ModelConfig(resolution=6.0, mesh_size=2, latent_size=latent, gnn_msg_steps=1,
+                                              hidden_layers=hidden, radius_query_fraction_edge_length=0.6)
+  for latent in (0, 513, 1024):
+    with pytest.raises(NotImplementedError, match="1 .. 512"):
+      gcm.GraphCast(mk(latent, 1), gcm.TASK_13, params={})
+  with pytest.raises(NotImplementedError, match="hidden_layers"):
+    gcm.GraphCast(mk(512, 0), gcm.TASK_13, params={})
+  c_out = gcm.num_output_channels(gcm.TASK_13)
+  params = gparams.random_params(183, c_out, 256, 1)
+  for cfg in (mk(512, 1), mk(256, 2)):          # the tree is a (256, 1) model's
+    model = gcm.GraphCast(cfg, gcm.TASK_13, params=params)
+    with pytest.raises(ValueError, match="latent_size=256, hidden_layers=1"):
+      model._check_params_fit_the_config()
+  gcm.GraphCast(mk(256, 1), gcm.TASK_13, params=params)._check_params_fit_the_config()
